@@ -1,0 +1,257 @@
+"""ctypes binding of liblora_hip.so (C-ABI declared in include/lora_hip.h).
+
+Thin by design: tensors in, raw device pointers + sizes + the current HIP stream out.  There is no
+fallback: if the library is missing, or a call returns a non-zero status, a RuntimeError is raised.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "liblora_hip.so")
+_lib = None
+_lock = threading.Lock()
+
+ABI_VERSION = 1
+PROF_KINDS = 4
+PROF_KIND_NAMES = ("lora_linear_fwd", "lora_linear_bwd_input", "lora_linear_bwd_params", "ddpm_mse_fwd_bwd")
+
+_DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+_vp, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+
+
+class ProfTotals(ctypes.Structure):
+    _fields_ = [
+        ("launches", _i64 * PROF_KINDS),
+        ("ms", ctypes.c_double * PROF_KINDS),
+        ("bytes", ctypes.c_double * PROF_KINDS),
+        ("flops", ctypes.c_double * PROF_KINDS),
+    ]
+
+
+# symbol -> (restype, argtypes); must list every function include/lora_hip.h declares
+SIGNATURES = {
+    "lora_version": (_i32, []),
+    "lora_status_string": (ctypes.c_char_p, [_i32]),
+    "lora_linear_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "lora_linear_bwd_input": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "lora_linear_bwd_params": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "ddpm_mse_fwd_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i64, _i64, _f32, _f32, _vp, _vp, _vp, _i32, _vp]),
+    "lora_mse_workspace_bytes": (_i64, []),
+    "lora_mask_prepare": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "lora_merge_weight": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "lora_cast_matrix": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "lora_grad_sqnorm": (_i32, [_vp, _i64, _f32, _vp, _vp, _vp]),
+    "lora_sqnorm_workspace_bytes": (_i64, []),
+    "lora_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
+    "ddpm_add_noise": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
+    "lora_prof_enable": (_i32, [_i32]),
+    "lora_prof_collect": (_i32, [ctypes.POINTER(ProfTotals)]),
+}
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def lib():
+    """Loads the library once.  Raises RuntimeError (never falls back) when it is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                f"diffusion_finetuning_amd: native library {_LIB_PATH} not found. Build it with "
+                "`python -m diffusion_finetuning_amd.build_native` (needs hipcc, targets gfx950). "
+                "There is no CPU or PyTorch fallback for the LoRA hot path."
+            )
+        handle = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        if handle.lora_version() != ABI_VERSION:
+            raise RuntimeError(
+                f"diffusion_finetuning_amd: {_LIB_PATH} has ABI {handle.lora_version()}, expected {ABI_VERSION}; rebuild it"
+            )
+        _lib = handle
+    return _lib
+
+
+def _check(status: int, what: str) -> None:
+    if status != 0:
+        msg = lib().lora_status_string(status).decode()
+        if status == -2:
+            raise ValueError(f"{what}: {msg}")
+        raise RuntimeError(f"{what} failed with status {status}: {msg}")
+
+
+def dtype_code(dtype: torch.dtype) -> int:
+    try:
+        return _DTYPE_CODE[dtype]
+    except KeyError:
+        raise RuntimeError(f"diffusion_finetuning_amd: unsupported dtype {dtype} (float32, float16, bfloat16 only)")
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def _require_device(*tensors) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "diffusion_finetuning_amd: the LoRA hot path runs only on a HIP device (MI355X); got a "
+                f"{t.device} tensor. Move the model and inputs to 'cuda'. There is no CPU fallback."
+            )
+
+
+def lora_linear_fwd(x2, w, bias, a, b, scale: float):
+    """x2 [M,K], w [N,K], bias [N]|None (dtype of x2); a [r,K], b [N,r] fp32. Returns (y [M,N], T [M,r] fp32)."""
+    _require_device(x2, w, bias, a, b)
+    M, K = x2.shape
+    N, r = b.shape
+    y = torch.empty((M, N), dtype=x2.dtype, device=x2.device)
+    t = torch.empty((M, r), dtype=torch.float32, device=x2.device)
+    _check(
+        lib().lora_linear_fwd(_ptr(x2), _ptr(w), _ptr(bias), _ptr(a), _ptr(b), _ptr(y), _ptr(t), M, K, N, r,
+                              float(scale), dtype_code(x2.dtype), _stream(x2)),
+        "lora_linear_fwd",
+    )
+    return y, t
+
+
+def lora_linear_bwd_input(dy2, wt, a, b, scale: float, need_dx: bool):
+    """dy2 [M,N]; wt [K,N] (= Wᵀ) or None when need_dx is False. Returns (dx [M,K]|None, U [M,r] fp32)."""
+    _require_device(dy2, wt, a, b)
+    M, N = dy2.shape
+    r, K = a.shape
+    dx = torch.empty((M, K), dtype=dy2.dtype, device=dy2.device) if need_dx else None
+    u = torch.empty((M, r), dtype=torch.float32, device=dy2.device)
+    _check(
+        lib().lora_linear_bwd_input(_ptr(dy2), _ptr(wt), _ptr(a), _ptr(b), _ptr(dx), _ptr(u), M, K, N, r,
+                                    float(scale), dtype_code(dy2.dtype), _stream(dy2)),
+        "lora_linear_bwd_input",
+    )
+    return dx, u
+
+
+def lora_linear_bwd_params(dy2, x2, t, u, ga, gb, scale: float):
+    """Accumulates into ga [r,K], gb [N,r] (fp32, caller-zeroed)."""
+    _require_device(dy2, x2, t, u, ga, gb)
+    M, N = dy2.shape
+    r, K = ga.shape
+    _check(
+        lib().lora_linear_bwd_params(_ptr(dy2), _ptr(x2), _ptr(t), _ptr(u), _ptr(ga), _ptr(gb), M, K, N, r,
+                                     float(scale), dtype_code(dy2.dtype), _stream(dy2)),
+        "lora_linear_bwd_params",
+    )
+
+
+_ws_cache = {}
+
+
+def _workspace(device, nbytes: int, tag: str):
+    key = (device, tag, torch.cuda.current_stream(device).cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def ddpm_mse_fwd_bwd(pred, target, mask, n_inst: int, n_prior: int, prior_weight: float, grad_scale: float,
+                     want_grad: bool = True):
+    """pred/target [rows, C, H, W] contiguous, same dtype; mask fp32 [rows,1,H,W] (normalised) or None.
+    Returns (loss fp32 scalar tensor, dpred|None)."""
+    _require_device(pred, target, mask)
+    rows = pred.shape[0]
+    assert rows == n_inst + n_prior
+    per_row = pred[0].numel()
+    hw = pred.shape[-1] * pred.shape[-2]
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    dpred = torch.empty_like(pred) if want_grad else None
+    ws = _workspace(pred.device, int(lib().lora_mse_workspace_bytes()), "mse")
+    _check(
+        lib().ddpm_mse_fwd_bwd(_ptr(pred), _ptr(target), _ptr(mask), n_inst, n_prior, per_row, hw,
+                               float(prior_weight), float(grad_scale), _ptr(loss), _ptr(dpred), _ptr(ws),
+                               dtype_code(pred.dtype), _stream(pred)),
+        "ddpm_mse_fwd_bwd",
+    )
+    return loss, dpred
+
+
+def lora_mask_prepare(mask_in, h: int, w: int):
+    _require_device(mask_in)
+    B, _, hin, win = mask_in.shape
+    out = torch.empty((B, 1, h, w), dtype=torch.float32, device=mask_in.device)
+    _check(lib().lora_mask_prepare(_ptr(mask_in), _ptr(out), B, hin, win, h, w, _stream(mask_in)), "lora_mask_prepare")
+    return out
+
+
+def lora_merge_weight(w, a, b, alpha: float) -> None:
+    _require_device(w, a, b)
+    N, K = w.shape
+    r = a.shape[0]
+    _check(lib().lora_merge_weight(_ptr(w), _ptr(a), _ptr(b), K, N, r, float(alpha), dtype_code(w.dtype), _stream(w)),
+           "lora_merge_weight")
+
+
+def lora_cast_matrix(src, dst_dtype: torch.dtype, transpose: bool):
+    _require_device(src)
+    rows, cols = src.shape
+    dst = torch.empty((cols, rows) if transpose else (rows, cols), dtype=dst_dtype, device=src.device)
+    _check(lib().lora_cast_matrix(_ptr(src), _ptr(dst), rows, cols, dtype_code(src.dtype), dtype_code(dst_dtype),
+                                  int(transpose), _stream(src)), "lora_cast_matrix")
+    return dst
+
+
+def lora_grad_sqnorm(grad, grad_mul: float, norm_out) -> None:
+    _require_device(grad, norm_out)
+    ws = _workspace(grad.device, int(lib().lora_sqnorm_workspace_bytes()), "sqnorm")
+    _check(lib().lora_grad_sqnorm(_ptr(grad), grad.numel(), float(grad_mul), _ptr(norm_out), _ptr(ws), _stream(grad)),
+           "lora_grad_sqnorm")
+
+
+def lora_adamw_step(param, grad, exp_avg, exp_avg_sq, norm_in, grad_mul, max_norm, lr, beta1, beta2, eps,
+                    weight_decay, step: int) -> None:
+    _require_device(param, grad, exp_avg, exp_avg_sq, norm_in)
+    _check(lib().lora_adamw_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(),
+                                 _ptr(norm_in), float(grad_mul), float(max_norm), float(lr), float(beta1),
+                                 float(beta2), float(eps), float(weight_decay), int(step), _stream(param)),
+           "lora_adamw_step")
+
+
+def ddpm_add_noise(x0, eps, t, sqrt_acp, sqrt_1macp, out_dtype: torch.dtype, v_prediction: bool, want_target=True):
+    _require_device(x0, eps, t, sqrt_acp, sqrt_1macp)
+    B = x0.shape[0]
+    per_row = x0[0].numel()
+    noisy = torch.empty(x0.shape, dtype=out_dtype, device=x0.device)
+    target = torch.empty(x0.shape, dtype=out_dtype, device=x0.device) if want_target else None
+    _check(lib().ddpm_add_noise(_ptr(x0), _ptr(eps), _ptr(t), _ptr(sqrt_acp), _ptr(sqrt_1macp), _ptr(noisy),
+                                _ptr(target), B, per_row, int(v_prediction), dtype_code(out_dtype), _stream(x0)),
+           "ddpm_add_noise")
+    return noisy, target
+
+
+def prof_enable(capacity: int) -> None:
+    _check(lib().lora_prof_enable(int(capacity)), "lora_prof_enable")
+
+
+def prof_collect():
+    tot = ProfTotals()
+    _check(lib().lora_prof_collect(ctypes.byref(tot)), "lora_prof_collect")
+    return {
+        PROF_KIND_NAMES[k]: {"launches": int(tot.launches[k]), "ms": float(tot.ms[k]), "bytes": float(tot.bytes[k]),
+                             "flops": float(tot.flops[k])}
+        for k in range(PROF_KINDS)
+    }

@@ -1,0 +1,258 @@
+// Fused gradient clipping + AdamW over the flat LoRA slab, weight merge and operand cache builders.
+//   clip + AdamW : training_scripts/train_lora_dreambooth.py:878-888, lora_diffusion/cli_lora_pti.py:448-451
+//                  (torch.nn.utils.clip_grad_norm_ and torch.optim.AdamW semantics, restated)
+//   merge        : lora_diffusion/lora.py:410-424 (weight_apply_lora)
+// The 288 LoRA tensors of an SD1.5 UNet live in ONE fp32 slab (parameters, gradients and both Adam
+// moments each), so the whole optimizer step is two HBM-streaming launches instead of hundreds.
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxBlocks = 1024;
+
+__device__ __forceinline__ float block_sum_256(float v, float* s_wave) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) s_wave[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x == 0) t = (s_wave[0] + s_wave[1]) + (s_wave[2] + s_wave[3]);
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* g, int64_t n, float mul, float* norm_out,
+                                                          float* partials, float* flags, unsigned* ticket) {
+    __shared__ float s_wave[4];
+    __shared__ bool s_last;
+    float local = 0.f, bad = 0.f;
+    const int64_t nvec = n >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const float4 v = g4[i];
+        const float a = v.x * mul, b = v.y * mul, c = v.z * mul, d = v.w * mul;
+        local = fmaf(a, a, local);
+        local = fmaf(b, b, local);
+        local = fmaf(c, c, local);
+        local = fmaf(d, d, local);
+        if (!(isfinite(a) && isfinite(b) && isfinite(c) && isfinite(d))) bad = 1.f;
+    }
+    if (blockIdx.x == 0) {
+        for (int64_t i = (nvec << 2) + threadIdx.x; i < n; i += 256) {
+            const float a = g[i] * mul;
+            local = fmaf(a, a, local);
+            if (!isfinite(a)) bad = 1.f;
+        }
+    }
+    const float bsum = block_sum_256(local, s_wave);
+    const float bbad = block_sum_256(bad, s_wave);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = bsum;
+        flags[blockIdx.x] = bbad;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = (t == gridDim.x - 1);
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (s_last) {
+        float t = 0.f, f = 0.f;
+        for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) {
+            t += partials[i];
+            f += flags[i];
+        }
+        t = block_sum_256(t, s_wave);
+        f = block_sum_256(f, s_wave);
+        if (threadIdx.x == 0) {
+            norm_out[0] = t;
+            norm_out[1] = (f != 0.f || !isfinite(t)) ? 1.f : 0.f;
+        }
+    }
+}
+
+struct AdamParams {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    int64_t n;
+    const float* norm_in;
+    float grad_mul, max_norm, lr, beta1, beta2, eps, wd;
+    float bc1, bc2_sqrt;  // 1-β1^t, sqrt(1-β2^t)
+};
+
+// torch.optim.AdamW (single-tensor path) per element, in this order:
+//   p *= 1 - lr·wd ; m = lerp(m, g, 1-β1) ; v = β2·v + (1-β2)·g² ;
+//   denom = sqrt(v)/sqrt(1-β2^t) + eps ; p -= (lr/(1-β1^t)) · m/denom
+__global__ __launch_bounds__(256) void adamw_kernel(AdamParams a) {
+    float clip = 1.f;
+    if (a.norm_in) {
+        if (a.norm_in[1] != 0.f) return;  // overflow: skip the step (GradScaler semantics)
+        if (a.max_norm > 0.f) {
+            const float c = a.max_norm / (sqrtf(a.norm_in[0]) + 1e-6f);
+            clip = c < 1.f ? c : 1.f;
+        }
+    }
+    const float gm = a.grad_mul * clip;
+    const float step_size = a.lr / a.bc1;
+    const float decay = 1.f - a.lr * a.wd;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
+        const float g = a.g[i] * gm;
+        float p = a.p[i] * decay;
+        float m = a.m[i];
+        m = m + (g - m) * (1.f - a.beta1);
+        const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
+        const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+        p = p - step_size * (m / denom);
+        a.p[i] = p;
+        a.m[i] = m;
+        a.v[i] = v;
+    }
+}
+
+// weight_apply_lora, op-by-op rounding as the reference: (B@A) in fp32 → .type(W.dtype) → ·α → + W.
+template <typename T>
+__global__ __launch_bounds__(256) void merge_kernel(T* W, const float* A, const float* B, int K, int N, int r,
+                                                    float alpha) {
+    const int64_t total = (int64_t)N * K;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int n = (int)(i / K), k = (int)(i - (int64_t)n * K);
+        float d = 0.f;
+        for (int j = 0; j < r; ++j) d = fmaf(B[(int64_t)n * r + j], A[(int64_t)j * K + k], d);
+        const T dt = from_f32<T>(d);
+        const T upd = from_f32<T>(alpha * to_f32<T>(dt));
+        W[i] = from_f32<T>(to_f32<T>(W[i]) + to_f32<T>(upd));
+    }
+}
+
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void cast_matrix_kernel(const S* src, D* dst, int64_t rows, int64_t cols,
+                                                          int transpose) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int64_t r = r0 + ty + i, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + i][tx] = to_f32<S>(src[r * cols + c]);
+    }
+    __syncthreads();
+    if (transpose) {
+#pragma unroll
+        for (int i = 0; i < 32; i += 8) {
+            const int64_t c = c0 + ty + i, r = r0 + tx;  // dst[c, r]
+            if (r < rows && c < cols) dst[c * rows + r] = from_f32<D>(tile[tx][ty + i]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 32; i += 8) {
+            const int64_t r = r0 + ty + i, c = c0 + tx;
+            if (r < rows && c < cols) dst[r * cols + c] = from_f32<D>(tile[ty + i][tx]);
+        }
+    }
+}
+
+template <typename S>
+int cast_dispatch_dst(const void* src, void* dst, int64_t rows, int64_t cols, int dst_dtype, int transpose,
+                      hipStream_t s) {
+    dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+    switch (dst_dtype) {
+        case LORA_F32:
+            hipLaunchKernelGGL((cast_matrix_kernel<S, float>), grid, dim3(256), 0, s, static_cast<const S*>(src),
+                               static_cast<float*>(dst), rows, cols, transpose);
+            break;
+        case LORA_F16:
+            hipLaunchKernelGGL((cast_matrix_kernel<S, half_t>), grid, dim3(256), 0, s, static_cast<const S*>(src),
+                               static_cast<half_t*>(dst), rows, cols, transpose);
+            break;
+        case LORA_BF16:
+            hipLaunchKernelGGL((cast_matrix_kernel<S, bf16_t>), grid, dim3(256), 0, s, static_cast<const S*>(src),
+                               static_cast<bf16_t*>(dst), rows, cols, transpose);
+            break;
+        default: return LORA_E_BADARG;
+    }
+    LORA_LAUNCH_CHECK();
+    return LORA_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t lora_sqnorm_workspace_bytes(void) { return 16 + 2 * kMaxBlocks * 4; }
+
+extern "C" int lora_grad_sqnorm(const float* grad, int64_t n, float grad_mul, float* norm_out, void* workspace,
+                                void* stream) {
+    if (!grad || !norm_out || !workspace || n < 1) return LORA_E_BADARG;
+    if (!aligned16(workspace) || !aligned16(grad)) return LORA_E_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(workspace, 0, 16, s) != hipSuccess) return LORA_E_LAUNCH;
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+    if (blocks < 1) blocks = 1;
+    char* ws = static_cast<char*>(workspace);
+    hipLaunchKernelGGL(grad_sqnorm_kernel, dim3((unsigned)blocks), dim3(256), 0, s, grad, n, grad_mul, norm_out,
+                       reinterpret_cast<float*>(ws + 16), reinterpret_cast<float*>(ws + 16 + kMaxBlocks * 4),
+                       reinterpret_cast<unsigned*>(ws));
+    LORA_LAUNCH_CHECK();
+    return LORA_OK;
+}
+
+extern "C" int lora_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                               const float* norm_in, float grad_mul, float max_norm, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, int step, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n < 1 || step < 1) return LORA_E_BADARG;
+    AdamParams a{};
+    a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = n; a.norm_in = norm_in;
+    a.grad_mul = grad_mul; a.max_norm = max_norm; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2;
+    a.eps = eps; a.wd = weight_decay;
+    // bias corrections in double on the host, as torch does with python floats
+    a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    LORA_LAUNCH_CHECK();
+    return LORA_OK;
+}
+
+extern "C" int lora_merge_weight(void* W, const float* A, const float* B, int K, int N, int r, float alpha,
+                                 int dtype, void* stream) {
+    if (!W || !A || !B || K < 1 || N < 1) return LORA_E_BADARG;
+    if (r < 1 || r > (K < N ? K : N)) return LORA_E_RANK;
+    int64_t blocks = ((int64_t)N * K + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case LORA_F32:
+            hipLaunchKernelGGL(merge_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<float*>(W), A,
+                               B, K, N, r, alpha);
+            break;
+        case LORA_F16:
+            hipLaunchKernelGGL(merge_kernel<half_t>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<half_t*>(W),
+                               A, B, K, N, r, alpha);
+            break;
+        case LORA_BF16:
+            hipLaunchKernelGGL(merge_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<bf16_t*>(W),
+                               A, B, K, N, r, alpha);
+            break;
+        default: return LORA_E_BADARG;
+    }
+    LORA_LAUNCH_CHECK();
+    return LORA_OK;
+}
+
+extern "C" int lora_cast_matrix(const void* src, void* dst, int64_t rows, int64_t cols, int src_dtype,
+                                int dst_dtype, int transpose, void* stream) {
+    if (!src || !dst || rows < 1 || cols < 1) return LORA_E_BADARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (src_dtype) {
+        case LORA_F32: return cast_dispatch_dst<float>(src, dst, rows, cols, dst_dtype, transpose, s);
+        case LORA_F16: return cast_dispatch_dst<half_t>(src, dst, rows, cols, dst_dtype, transpose, s);
+        case LORA_BF16: return cast_dispatch_dst<bf16_t>(src, dst, rows, cols, dst_dtype, transpose, s);
+        default: return LORA_E_BADARG;
+    }
+}

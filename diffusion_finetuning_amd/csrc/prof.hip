@@ -1,0 +1,105 @@
+// Library identity + the optional launch profiler (HIP events on the caller's stream).
+// The profiler is measurement infrastructure for bench.py's `roofline` object: it is the only
+// mutable global state in the library, guarded by a mutex, and inert unless enabled.
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+struct ProfRecord {
+    hipEvent_t e0, e1;
+    int kind;
+    double bytes, flops;
+};
+struct ProfState {
+    std::mutex mu;
+    std::vector<ProfRecord> rec;  // preallocated events
+    int used = 0;
+    bool on = false;
+};
+ProfState& prof() {
+    static ProfState s;
+    return s;
+}
+
+}  // namespace
+
+int lora_prof_begin(int kind, double bytes, double flops, hipStream_t stream) {
+    ProfState& s = prof();
+    if (!s.on) return -1;
+    std::lock_guard<std::mutex> lk(s.mu);
+    if (!s.on || s.used >= (int)s.rec.size()) return -1;
+    const int slot = s.used++;
+    ProfRecord& r = s.rec[slot];
+    r.kind = kind;
+    r.bytes = bytes;
+    r.flops = flops;
+    (void)hipEventRecord(r.e0, stream);
+    return slot;
+}
+
+void lora_prof_end(int slot, hipStream_t stream) {
+    if (slot < 0) return;
+    ProfState& s = prof();
+    std::lock_guard<std::mutex> lk(s.mu);
+    if (slot < s.used) (void)hipEventRecord(s.rec[slot].e1, stream);
+}
+
+extern "C" int lora_version(void) { return LORA_HIP_ABI_VERSION; }
+
+extern "C" const char* lora_status_string(int status) {
+    switch (status) {
+        case LORA_OK: return "ok";
+        case LORA_E_BADARG: return "bad argument (null pointer, non-positive size or unknown dtype)";
+        case LORA_E_RANK: return "LoRA rank must be >= 1 and <= min(in_features, out_features)";
+        case LORA_E_ALIGN: return "pointer must be 16-byte aligned";
+        case LORA_E_LAUNCH: return "HIP kernel launch failed";
+        case LORA_E_UNSUPPORTED: return "unsupported combination";
+        default: return "unknown status";
+    }
+}
+
+extern "C" int lora_prof_enable(int capacity) {
+    ProfState& s = prof();
+    std::lock_guard<std::mutex> lk(s.mu);
+    for (auto& r : s.rec) {
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    s.rec.clear();
+    s.used = 0;
+    s.on = false;
+    if (capacity <= 0) return LORA_OK;
+    s.rec.resize(capacity);
+    for (auto& r : s.rec) {
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return LORA_E_LAUNCH;
+    }
+    s.on = true;
+    return LORA_OK;
+}
+
+extern "C" int lora_prof_collect(lora_prof_totals* out) {
+    if (!out) return LORA_E_BADARG;
+    ProfState& s = prof();
+    std::lock_guard<std::mutex> lk(s.mu);
+    for (int k = 0; k < LORA_PROF_KINDS; ++k) {
+        out->launches[k] = 0;
+        out->ms[k] = out->bytes[k] = out->flops[k] = 0.0;
+    }
+    for (int i = 0; i < s.used; ++i) {
+        ProfRecord& r = s.rec[i];
+        if (hipEventSynchronize(r.e1) != hipSuccess) return LORA_E_LAUNCH;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) return LORA_E_LAUNCH;
+        if (r.kind >= 0 && r.kind < LORA_PROF_KINDS) {
+            out->launches[r.kind] += 1;
+            out->ms[r.kind] += ms;
+            out->bytes[r.kind] += r.bytes;
+            out->flops[r.kind] += r.flops;
+        }
+    }
+    s.used = 0;
+    return LORA_OK;
+}

@@ -1,0 +1,172 @@
+/*
+ * lora_hip.h — C-ABI of liblora_hip.so, the gfx950 (MI355X) implementation of the
+ * LoRA fine-tuning hot path of levayz/diffusion_finetuning (`lora_diffusion`).
+ *
+ * The reference has no native code: every entry point below replaces a group of
+ * stock-PyTorch calls made by the reference's Python.  Each declaration cites the
+ * reference lines it stands in for (paths relative to the reference repo root).
+ *
+ * Conventions (all entry points)
+ *   - plain C: raw DEVICE pointers, sizes, a `void* stream` (hipStream_t; NULL = null stream).
+ *   - row-major, densely packed tensors unless a leading dimension is given.
+ *   - nothing is allocated, retained or freed by the library; kernels are enqueued on
+ *     `stream` and the call returns without synchronising.  Re-entrant, no mutable globals
+ *     (the optional launch profiler below is the one exception and is off by default).
+ *   - return value: LORA_OK (0) or a negative LORA_E_* code; never throws, never aborts.
+ *   - `dtype` selects the storage/compute type of the big operands (X, W, Y, dY, dX, pred ...):
+ *     LORA_F32 / LORA_F16 / LORA_BF16.  Accumulation is always fp32.  The rank-r factors,
+ *     their gradients and the saved rank-r activations are ALWAYS fp32 ("master" precision).
+ *
+ * Notation: X[M,K] input rows, W[N,K] frozen base weight, b[N] bias, A[r,K] = lora_down.weight,
+ * B[N,r] = lora_up.weight, s = LoraInjectedLinear.scale, T[M,r] = X·Aᵀ.
+ */
+#ifndef LORA_HIP_H
+#define LORA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LORA_HIP_ABI_VERSION 1
+
+enum lora_dtype { LORA_F32 = 0, LORA_F16 = 1, LORA_BF16 = 2 };
+
+enum lora_status {
+    LORA_OK = 0,
+    LORA_E_BADARG = -1,      /* null pointer / non-positive size / unknown dtype            */
+    LORA_E_RANK = -2,        /* r < 1 or r > min(K,N)  (reference: ValueError, lora.py:36-39) */
+    LORA_E_ALIGN = -3,       /* pointer not 16-byte aligned where the kernel needs it        */
+    LORA_E_LAUNCH = -4,      /* hipLaunch / hipGetLastError reported a failure               */
+    LORA_E_UNSUPPORTED = -5  /* combination not implemented                                  */
+};
+
+/* ABI version of the loaded library (== LORA_HIP_ABI_VERSION it was built with). */
+int lora_version(void);
+
+/* Static, human-readable text for a lora_status code. */
+const char* lora_status_string(int status);
+
+/*
+ * Forward of LoraInjectedLinear.forward — lora_diffusion/lora.py:49-50
+ *     Y = X·Wᵀ + b + s·((X·Aᵀ)·Bᵀ)
+ * replaces F.linear ×3 + mul + add (5 launches + the [M,N] LoRA temporary) with one kernel.
+ * T_out (nullable) receives T = X·Aᵀ [M,r] fp32 for the backward.
+ */
+int lora_linear_fwd(const void* X, const void* W, const void* bias /* nullable */,
+                    const float* A, const float* B, void* Y, float* T_out /* nullable */,
+                    int64_t M, int K, int N, int r, float scale, int dtype, void* stream);
+
+/*
+ * Backward w.r.t. the input — autograd of lora.py:49-50 as driven by
+ * training_scripts/train_lora_dreambooth.py:877 (accelerator.backward), base W frozen (:595):
+ *     U  = dY·B                         [M,r]  (written to U_out, fp32, unscaled)
+ *     dX = dY·W + s·U·A                 [M,K]  (skipped when dX == NULL: attn2 to_k/to_v with a
+ *                                               frozen text encoder need no input gradient)
+ * Wt is the frozen weight stored TRANSPOSED, Wt[K,N] = Wᵀ, so that the contraction index n is
+ * contiguous for both operands (the caller caches Wt once per frozen layer).
+ */
+int lora_linear_bwd_input(const void* dY, const void* Wt, const float* A, const float* B,
+                          void* dX /* nullable */, float* U_out, int64_t M, int K, int N, int r,
+                          float scale, int dtype, void* stream);
+
+/*
+ * Backward w.r.t. the LoRA factors (no grad for W or b: lora.py:179-180 set requires_grad only on
+ * lora_up / lora_down; train_lora_dreambooth.py:595 freezes the rest):
+ *     gB += s·dYᵀ·T      [N,r]
+ *     gA += s·Uᵀ·X       [r,K]
+ * ACCUMULATES (fp32 atomic add) into gA / gB, which the caller zeroes once per optimizer step —
+ * they are normally slices of one flat gradient slab that is also the RCCL all-reduce buffer.
+ */
+int lora_linear_bwd_params(const void* dY, const void* X, const float* T, const float* U,
+                           float* gA, float* gB, int64_t M, int K, int N, int r, float scale,
+                           int dtype, void* stream);
+
+/*
+ * DDPM noise-prediction loss, forward + gradient in one pass —
+ * training_scripts/train_lora_dreambooth.py:855-875 and lora_diffusion/cli_lora_pti.py:222-247.
+ *   rows [0, n_inst)            instance part : mean_b(mean_chw((p-t)²))
+ *   rows [n_inst, n_inst+n_prior) prior part  : prior_weight · mean((p-t)²)     (n_prior may be 0)
+ *   mask (nullable, fp32 [rows, 1, H, W] broadcast over `channels`, already normalised by
+ *   lora_mask_prepare): p and t are multiplied by it first (cli_lora_pti.py:243-247).
+ * loss_out[0] = loss (fp32).  dpred (nullable, same dtype as pred) = grad_scale · dloss/dpred.
+ * workspace: at least lora_mse_workspace_bytes() bytes, 16-byte aligned; the call zeroes what it uses.
+ */
+int ddpm_mse_fwd_bwd(const void* pred, const void* target, const float* mask /* nullable */,
+                     int n_inst, int n_prior, int64_t per_row /* C·H·W */, int64_t hw /* H·W */,
+                     float prior_weight, float grad_scale, float* loss_out, void* dpred /* nullable */,
+                     void* workspace, int dtype, void* stream);
+int64_t lora_mse_workspace_bytes(void);
+
+/*
+ * Mask preparation of cli_lora_pti.py:222-241:
+ *   out = nearest_resize(mask[B,1,Hin,Win] -> [B,1,H,W]) + 0.05 ;  out /= mean(out)
+ * mask_in / mask_out fp32.  Single launch, deterministic.
+ */
+int lora_mask_prepare(const float* mask_in, float* mask_out, int B, int Hin, int Win, int H, int W,
+                      void* stream);
+
+/*
+ * weight_apply_lora — lora_diffusion/lora.py:410-424:   W ← W + (α·(B·A)).type(W.dtype)
+ * In place on W[N,K] (dtype), A[r,K], B[N,r] fp32.
+ */
+int lora_merge_weight(void* W, const float* A, const float* B, int K, int N, int r, float alpha,
+                      int dtype, void* stream);
+
+/* Out-of-place transpose+cast helper used to build the cached operands:
+ * dst[cols,rows] (dst_dtype) = src[rows,cols] (src_dtype)ᵀ ; transpose=0 gives a plain cast. */
+int lora_cast_matrix(const void* src, void* dst, int64_t rows, int64_t cols, int src_dtype,
+                     int dst_dtype, int transpose, void* stream);
+
+/*
+ * Fused clip_grad_norm_ + AdamW over the flat LoRA slab —
+ * training_scripts/train_lora_dreambooth.py:878-888 (clip_grad_norm_(…, max_grad_norm); optimizer.step())
+ * and lora_diffusion/cli_lora_pti.py:448-451.
+ *   lora_grad_sqnorm : norm_out[0] = Σ (grad_mul·g)² over n elements (deterministic two-level sum),
+ *                      norm_out[1] = 1.0f if any element is non-finite else 0.0f.
+ *   lora_adamw_step  : g' = grad_mul·g·min(1, max_norm/(sqrt(norm_in[0])+1e-6))   (max_norm<=0: no clip)
+ *                      torch.optim.AdamW update (decoupled weight decay, bias correction with `step`),
+ *                      skipped entirely when norm_in[1] != 0 (GradScaler-style overflow skip).
+ * `grad_mul` carries 1/world_size (mean all-reduce) and 1/loss_scale.
+ */
+int lora_grad_sqnorm(const float* grad, int64_t n, float grad_mul, float* norm_out, void* workspace,
+                     void* stream);
+int64_t lora_sqnorm_workspace_bytes(void);
+int lora_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                    const float* norm_in /* nullable: no clip, no skip */, float grad_mul, float max_norm,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                    void* stream);
+
+/*
+ * Step prologue — training_scripts/train_lora_dreambooth.py:824-853 (add_noise / target selection)
+ * with the DDPM definitions (diffusers DDPMScheduler, not vendored in the reference):
+ *     noisy  = sqrt_acp[t_b]·x0 + sqrt_1macp[t_b]·eps
+ *     target = eps                                   (v_prediction == 0)
+ *            = sqrt_acp[t_b]·eps − sqrt_1macp[t_b]·x0 (v_prediction != 0)
+ * x0, eps fp32 [B, per_row]; t int64 [B]; tables fp32 [T]; noisy/target in `dtype`.
+ */
+int ddpm_add_noise(const float* x0, const float* eps, const int64_t* t, const float* sqrt_acp,
+                   const float* sqrt_1macp, void* noisy, void* target, int B, int64_t per_row,
+                   int v_prediction, int dtype, void* stream);
+
+/*
+ * Launch profiler (measurement only; off by default).  When enabled every lora_linear_* call
+ * brackets its kernel with HIP events on the caller's stream and records (kind, algorithmic
+ * bytes, algorithmic flops).  lora_prof_collect synchronises the recorded events and returns
+ * per-kind totals.  kind: 0 = fwd, 1 = bwd_input, 2 = bwd_params, 3 = mse.
+ */
+#define LORA_PROF_KINDS 4
+typedef struct lora_prof_totals {
+    int64_t launches[LORA_PROF_KINDS];
+    double ms[LORA_PROF_KINDS];
+    double bytes[LORA_PROF_KINDS];
+    double flops[LORA_PROF_KINDS];
+} lora_prof_totals;
+int lora_prof_enable(int capacity /* max recorded launches; 0 disables and frees */);
+int lora_prof_collect(lora_prof_totals* out /* also resets the recording */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LORA_HIP_H */
