@@ -41,7 +41,7 @@ SIGNATURES = {
     "ddpm_mse_fwd_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i64, _i64, _f32, _f32, _vp, _vp, _vp, _i32, _vp]),
     "lora_mse_workspace_bytes": (_i64, []),
     "lora_mask_prepare": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
-    "lora_merge_weight": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "lora_merge_weight": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
     "lora_cast_matrix": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
     "lora_grad_sqnorm": (_i32, [_vp, _i64, _f32, _vp, _vp, _vp]),
     "lora_sqnorm_workspace_bytes": (_i64, []),
@@ -198,11 +198,13 @@ def lora_mask_prepare(mask_in, h: int, w: int):
     return out
 
 
-def lora_merge_weight(w, a, b, alpha: float) -> None:
+def lora_merge_weight(w, a, b, alpha: float, factor_dtype: torch.dtype = torch.float32) -> None:
+    """In place W += alpha*(b@a); a [r,K], b [N,r] fp32 copies of factors held in `factor_dtype`."""
     _require_device(w, a, b)
     N, K = w.shape
     r = a.shape[0]
-    _check(lib().lora_merge_weight(_ptr(w), _ptr(a), _ptr(b), K, N, r, float(alpha), dtype_code(w.dtype), _stream(w)),
+    _check(lib().lora_merge_weight(_ptr(w), _ptr(a), _ptr(b), K, N, r, float(alpha), dtype_code(w.dtype),
+                                   dtype_code(factor_dtype), _stream(w)),
            "lora_merge_weight")
 
 

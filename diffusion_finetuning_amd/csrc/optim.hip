@@ -118,12 +118,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamParams a) {
 // weight_apply_lora, op-by-op rounding as the reference: (B@A) in fp32 → .type(W.dtype) → ·α → + W.
 template <typename T>
 __global__ __launch_bounds__(256) void merge_kernel(T* W, const float* A, const float* B, int K, int N, int r,
-                                                    float alpha) {
+                                                    float alpha, int factor_dtype) {
     const int64_t total = (int64_t)N * K;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int n = (int)(i / K), k = (int)(i - (int64_t)n * K);
         float d = 0.f;
         for (int j = 0; j < r; ++j) d = fmaf(B[(int64_t)n * r + j], A[(int64_t)j * K + k], d);
+        if (factor_dtype == LORA_F16) d = to_f32<half_t>(from_f32<half_t>(d));
+        if (factor_dtype == LORA_BF16) d = to_f32<bf16_t>(from_f32<bf16_t>(d));
         const T dt = from_f32<T>(d);
         const T upd = from_f32<T>(alpha * to_f32<T>(dt));
         W[i] = from_f32<T>(to_f32<T>(W[i]) + to_f32<T>(upd));
@@ -220,7 +222,7 @@ extern "C" int lora_adamw_step(float* param, const float* grad, float* exp_avg, 
 }
 
 extern "C" int lora_merge_weight(void* W, const float* A, const float* B, int K, int N, int r, float alpha,
-                                 int dtype, void* stream) {
+                                 int dtype, int factor_dtype, void* stream) {
     if (!W || !A || !B || K < 1 || N < 1) return LORA_E_BADARG;
     if (r < 1 || r > (K < N ? K : N)) return LORA_E_RANK;
     int64_t blocks = ((int64_t)N * K + 255) / 256;
@@ -229,15 +231,15 @@ extern "C" int lora_merge_weight(void* W, const float* A, const float* B, int K,
     switch (dtype) {
         case LORA_F32:
             hipLaunchKernelGGL(merge_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<float*>(W), A,
-                               B, K, N, r, alpha);
+                               B, K, N, r, alpha, factor_dtype);
             break;
         case LORA_F16:
             hipLaunchKernelGGL(merge_kernel<half_t>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<half_t*>(W),
-                               A, B, K, N, r, alpha);
+                               A, B, K, N, r, alpha, factor_dtype);
             break;
         case LORA_BF16:
             hipLaunchKernelGGL(merge_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<bf16_t*>(W),
-                               A, B, K, N, r, alpha);
+                               A, B, K, N, r, alpha, factor_dtype);
             break;
         default: return LORA_E_BADARG;
     }

@@ -1,0 +1,195 @@
+"""Autograd front of the HIP hot path.
+
+`lora_linear(module, x)` is what `LoraInjectedLinear.forward` calls: one fused forward kernel, and in the
+backward one fused dX kernel plus one factor-gradient kernel (reference arithmetic: lora_diffusion/lora.py:49-50
+and its autograd).  `ddpm_mse_loss` is the fused loss of training_scripts/train_lora_dreambooth.py:855-875 and
+lora_diffusion/cli_lora_pti.py:222-247.
+
+Frozen operands are cached per module in the layouts the kernels want — W in the compute dtype and its
+transpose Wᵀ (so the backward contraction is contiguous too).  That costs 2× the frozen-weight bytes, which is
+nothing on a 288 GB part, and removes the per-call fp32→fp16 weight cast the reference pays under autocast.
+The cache is keyed on the weight's storage pointer, version counter, dtype and device, so `.to()`, `.half()`,
+`weight_apply_lora` or assigning a new Parameter invalidate it.
+"""
+import warnings
+
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import _native as nat
+
+_warned_trainable_base = False
+
+
+def _compute_dtype(weight: torch.Tensor) -> torch.dtype:
+    if torch.is_autocast_enabled("cuda"):
+        return torch.get_autocast_dtype("cuda")
+    return weight.dtype
+
+
+def _frozen_operands(module, cdtype: torch.dtype, need_wt: bool):
+    """Returns (W, Wᵀ|None, bias|None) in `cdtype`, building them once per (weight state, dtype)."""
+    lin = module.linear
+    w = lin.weight
+    b = lin.bias
+    key = (w.data_ptr(), w._version, w.dtype, w.device, cdtype,
+           None if b is None else (b.data_ptr(), b._version))
+    cache = module.__dict__.get("_dfa_cache")
+    if cache is None or cache["key"] != key:
+        wd = w.detach()
+        if not wd.is_contiguous():
+            wd = wd.contiguous()
+        cache = {
+            "key": key,
+            "w": wd if wd.dtype == cdtype else nat.lora_cast_matrix(wd, cdtype, False),
+            "wt": None,
+            "bias": None if b is None else b.detach().to(cdtype).contiguous(),
+        }
+        module.__dict__["_dfa_cache"] = cache
+    if need_wt and cache["wt"] is None:
+        cache["wt"] = nat.lora_cast_matrix(cache["w"], cdtype, True)
+    return cache["w"], cache["wt"], cache["bias"]
+
+
+def invalidate_weight_cache(model: torch.nn.Module) -> None:
+    """Drops every cached W/Wᵀ copy under `model` (call after mutating frozen weights through `.data`)."""
+    for m in model.modules():
+        m.__dict__.pop("_dfa_cache", None)
+
+
+def _as_f32(p: torch.Tensor) -> torch.Tensor:
+    p = p.detach()
+    if p.dtype != torch.float32:
+        p = p.float()
+    return p if p.is_contiguous() else p.contiguous()
+
+
+class _LoraLinearFn(torch.autograd.Function):
+    """y = x·Wᵀ + b + s·(x·Aᵀ)·Bᵀ with grads for x, A (down) and B (up) only."""
+
+    @staticmethod
+    def forward(ctx, x, down, up, w, wt, bias, scale, grad_sink):
+        K = w.shape[1]
+        N = w.shape[0]
+        x2 = x.reshape(-1, K)
+        if x2.dtype != w.dtype:
+            x2 = x2.to(w.dtype)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        a = _as_f32(down)
+        b = _as_f32(up)
+        y2, t = nat.lora_linear_fwd(x2, w, bias, a, b, scale)
+        ctx.save_for_backward(x2, a, b, t)
+        ctx.wt = wt
+        ctx.scale = float(scale)
+        ctx.x_shape = x.shape
+        ctx.x_dtype = x.dtype
+        ctx.factor_dtypes = (down.dtype, up.dtype)
+        ctx.grad_sink = grad_sink
+        return y2.view(*x.shape[:-1], N)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2, a, b, t = ctx.saved_tensors
+        N = b.shape[0]
+        need_dx = ctx.needs_input_grad[0]
+        need_factors = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dy2 = dy.reshape(-1, N)
+        if dy2.dtype != x2.dtype:
+            dy2 = dy2.to(x2.dtype)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        if need_dx and ctx.wt is None:
+            raise RuntimeError("lora_linear backward: Wᵀ operand was not prepared in forward")
+        dx2, u = nat.lora_linear_bwd_input(dy2, ctx.wt if need_dx else None, a, b, ctx.scale, need_dx)
+        g_down = g_up = None
+        if need_factors:
+            sink = ctx.grad_sink
+            if sink is not None:
+                # trainer mode: accumulate straight into the flat gradient slab (also the RCCL buffer)
+                nat.lora_linear_bwd_params(dy2, x2, t, u, sink[0], sink[1], ctx.scale)
+            else:
+                g_down = torch.zeros_like(a)
+                g_up = torch.zeros_like(b)
+                nat.lora_linear_bwd_params(dy2, x2, t, u, g_down, g_up, ctx.scale)
+                if ctx.factor_dtypes[0] != torch.float32:
+                    g_down = g_down.to(ctx.factor_dtypes[0])
+                if ctx.factor_dtypes[1] != torch.float32:
+                    g_up = g_up.to(ctx.factor_dtypes[1])
+        dx = None
+        if need_dx:
+            dx = dx2.view(ctx.x_shape)
+            if dx.dtype != ctx.x_dtype:
+                dx = dx.to(ctx.x_dtype)
+        return dx, g_down, g_up, None, None, None, None, None
+
+
+def lora_linear(module, x: torch.Tensor) -> torch.Tensor:
+    """Fused LoraInjectedLinear forward (lora_diffusion/lora.py:49-50) on the HIP device."""
+    global _warned_trainable_base
+    lin, down, up = module.linear, module.lora_down.weight, module.lora_up.weight
+    if not x.is_cuda or not lin.weight.is_cuda:
+        raise RuntimeError(
+            "LoraInjectedLinear.forward: the fused LoRA path runs only on a HIP device (MI355X); got input on "
+            f"{x.device} and weight on {lin.weight.device}. Move the model and inputs to 'cuda' — there is no CPU fallback."
+        )
+    if lin.weight.requires_grad and torch.is_grad_enabled() and not _warned_trainable_base:
+        _warned_trainable_base = True
+        warnings.warn(
+            "LoraInjectedLinear: the base weight has requires_grad=True, but this path treats W and b as frozen "
+            "(no ∇W/∇b are produced). Call model.requires_grad_(False) before inject_trainable_lora as the "
+            "reference trainers do."
+        )
+    cdtype = _compute_dtype(lin.weight)
+    need_wt = torch.is_grad_enabled() and x.requires_grad
+    w, wt, bias = _frozen_operands(module, cdtype, need_wt)
+    sink = module.__dict__.get("_dfa_grad_sink")
+    return _LoraLinearFn.apply(x, down, up, w, wt, bias, float(module.scale), sink)
+
+
+class _DDPMLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, mask, n_inst, n_prior, prior_weight):
+        p = pred if pred.is_contiguous() else pred.contiguous()
+        t = target.detach()
+        if t.dtype != p.dtype:
+            t = t.to(p.dtype)
+        if not t.is_contiguous():
+            t = t.contiguous()
+        loss, dpred = nat.ddpm_mse_fwd_bwd(p, t, mask, n_inst, n_prior, prior_weight, 1.0,
+                                           want_grad=ctx.needs_input_grad[0])
+        if dpred is not None:
+            ctx.save_for_backward(dpred)
+        return loss.reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        return dpred * g.to(dpred.dtype), None, None, None, None, None
+
+
+def ddpm_mse_loss(pred, target, *, with_prior_preservation=False, prior_loss_weight=1.0, mask=None):
+    """DDPM noise-prediction loss in one fused pass.
+
+    Plain:  mean((pred.float()-target.float())²)                       (train_lora_dreambooth.py:875)
+    Prior:  batch halves → instance mean-of-means + w·prior mean        (train_lora_dreambooth.py:855-873)
+    Mask:   `mask` is the RAW [B,1,8h,8w] mask of cli_lora_pti.py:222-241; it is resized (nearest), +0.05,
+            mean-normalised on the device and applied to pred and target (cli_lora_pti.py:243-247).
+    Returns a 0-d fp32 tensor that backpropagates into `pred`.
+    """
+    if not pred.is_cuda:
+        raise RuntimeError("ddpm_mse_loss runs only on a HIP device; there is no CPU fallback")
+    rows = pred.shape[0]
+    if with_prior_preservation:
+        if rows % 2 != 0:
+            raise ValueError("prior preservation needs an even batch (instance rows then class rows)")
+        n_inst = n_prior = rows // 2
+    else:
+        n_inst, n_prior = rows, 0
+    m = None
+    if mask is not None:
+        raw = mask.to(pred.device).reshape(rows, 1, pred.shape[2] * 8, pred.shape[3] * 8).float().contiguous()
+        m = nat.lora_mask_prepare(raw, pred.shape[2], pred.shape[3])
+    return _DDPMLossFn.apply(pred, target, m, n_inst, n_prior, float(prior_loss_weight))

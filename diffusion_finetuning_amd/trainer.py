@@ -1,0 +1,252 @@
+"""Step harness for the LoRA hot path: flat LoRA slab, fused loss, data-parallel exchange, fused clip+AdamW.
+
+Reproduces the per-step semantics of training_scripts/train_lora_dreambooth.py:811-888 (and the PTI tuning
+loop lora_diffusion/cli_lora_pti.py:438-451) on synthetic latents:
+
+    noisy = add_noise(latents, noise, t) ; pred = unet(noisy, t, ctx).sample ; target = noise | velocity
+    loss  = mse (+ prior preservation | mask) ; backward ; [DDP mean all-reduce of LoRA grads]
+    clip_grad_norm_(·, max_grad_norm) ; AdamW.step ; zero_grad
+
+MI355X-first layout: every LoRA factor of the model lives in ONE fp32 slab in enumeration order
+[up0, down0, up1, down1, ...] (the order of `inject_trainable_lora`'s return value and of the `.pt` file), with
+matching slabs for gradients and both Adam moments.  The backward kernels accumulate straight into the gradient
+slab, which is also the RCCL send/receive buffer — no packing, one or two collectives per step instead of 288 —
+and the optimizer is two launches over the slab.  Data parallelism is one process per GPU over
+`torch.distributed` (backend "nccl" = RCCL over xGMI); only the LoRA gradients (≈5 MB at rank 4) ever cross GPUs.
+"""
+import math
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import _native as nat
+from .lora import LoraInjectedLinear
+
+
+def ddpm_tables(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, device="cpu"):
+    """sqrt(ᾱ_t), sqrt(1-ᾱ_t) of the SD "scaled_linear" DDPM schedule (the constants come from the model's hub
+    config, which is not part of the reference repo)."""
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+    acp = torch.cumprod(1.0 - betas, dim=0)
+    return acp.sqrt().to(device), (1.0 - acp).sqrt().to(device)
+
+
+def lora_layers(model: nn.Module) -> List[LoraInjectedLinear]:
+    """All LoraInjectedLinear modules in `model.modules()` order — for an injected model this is the
+    enumeration order of lora.py:78-114, because every target is visited under its first matching ancestor."""
+    return [m for m in model.modules() if isinstance(m, LoraInjectedLinear)]
+
+
+class LoraSlab:
+    """Re-homes every LoRA factor of `models` into one flat fp32 parameter slab (+ gradient slab).
+
+    The nn.Parameter objects stay the same (optimizers, generators and state_dict keep working); only their
+    storage moves.  Each layer gets `_dfa_grad_sink = (grad_down_view, grad_up_view)` so the backward kernel
+    accumulates in place, and `.grad` of each Parameter is a view of the gradient slab."""
+
+    def __init__(self, models: Sequence[nn.Module]):
+        self.layers: List[LoraInjectedLinear] = []
+        self.model_ranges: List[Tuple[int, int]] = []
+        for model in models:
+            start = sum(l.lora_up.weight.numel() + l.lora_down.weight.numel() for l in self.layers)
+            self.layers += lora_layers(model)
+            end = sum(l.lora_up.weight.numel() + l.lora_down.weight.numel() for l in self.layers)
+            self.model_ranges.append((start, end))
+        if not self.layers:
+            raise ValueError("No lora injected.")
+        device = self.layers[0].lora_up.weight.device
+        if device.type != "cuda":
+            raise RuntimeError("LoraSlab: the model must be on the HIP device")
+        total = sum(l.lora_up.weight.numel() + l.lora_down.weight.numel() for l in self.layers)
+        pad = (-total) % 4  # keep 16-byte granularity for vector loads
+        self.numel = total
+        self.params = torch.zeros(total + pad, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(total + pad, dtype=torch.float32, device=device)
+        self.offsets = []
+        off = 0
+        for layer in self.layers:
+            views = {}
+            for attr in ("lora_up", "lora_down"):  # file order: up then down
+                p = getattr(layer, attr).weight
+                n = p.numel()
+                pv = self.params[off:off + n].view(p.shape)
+                pv.copy_(p.detach().float())
+                p.data = pv
+                gv = self.grads[off:off + n].view(p.shape)
+                p.grad = gv
+                views[attr] = gv
+                self.offsets.append((off, n))
+                off += n
+            layer.__dict__["_dfa_grad_sink"] = (views["lora_down"], views["lora_up"])
+
+    def zero_grad(self):
+        self.grads.zero_()
+
+    def detach_sinks(self):
+        for layer in self.layers:
+            layer.__dict__.pop("_dfa_grad_sink", None)
+
+    def range_of(self, module: nn.Module) -> Tuple[int, int]:
+        """[start, end) of the slab covering the LoRA layers under `module` (must be contiguous)."""
+        inside = {id(l) for l in lora_layers(module)}
+        idx = [i for i, l in enumerate(self.layers) if id(l) in inside]
+        if not idx:
+            return (0, 0)
+        assert idx == list(range(idx[0], idx[-1] + 1)), "layers under the module are not contiguous in the slab"
+        return (self.offsets[2 * idx[0]][0], self.offsets[2 * idx[-1] + 1][0] + self.offsets[2 * idx[-1] + 1][1])
+
+
+class FusedClipAdamW:
+    """clip_grad_norm_ + torch.optim.AdamW over slab ranges, each range with its own lr / weight decay
+    (the reference builds one param group for the UNet and one for the text encoder,
+    train_lora_dreambooth.py:659-676)."""
+
+    def __init__(self, slab: LoraSlab, groups: Sequence[dict], betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0):
+        self.slab = slab
+        self.groups = [dict(g) for g in groups]  # {"range": (a,b), "lr": .., "weight_decay": ..}
+        self.betas, self.eps, self.max_grad_norm = betas, eps, max_grad_norm
+        self.exp_avg = torch.zeros_like(slab.params)
+        self.exp_avg_sq = torch.zeros_like(slab.params)
+        self.norm = torch.zeros(4, dtype=torch.float32, device=slab.params.device)
+        self.step_count = 0
+
+    def step(self, grad_mul: float = 1.0):
+        """One optimizer step on the current gradient slab; `grad_mul` = 1/(world_size·loss_scale)."""
+        s = self.slab
+        self.step_count += 1
+        nat.lora_grad_sqnorm(s.grads[: s.numel], grad_mul, self.norm)
+        for g in self.groups:
+            a, b = g["range"]
+            if b <= a:
+                continue
+            nat.lora_adamw_step(s.params[a:b], s.grads[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], self.norm,
+                                grad_mul, self.max_grad_norm, g["lr"], self.betas[0], self.betas[1], self.eps,
+                                g.get("weight_decay", 1e-2), self.step_count)
+
+    def grad_norm(self) -> float:
+        """Total (pre-clip) gradient L2 norm of the last step (host sync)."""
+        return math.sqrt(float(self.norm[0].item()))
+
+    def overflowed(self) -> bool:
+        return bool(self.norm[1].item() != 0.0)
+
+
+class SlabExchange:
+    """Synchronous data-parallel exchange of the flat gradient slab: SUM all-reduce in at most two buckets
+    (the mean's 1/world is folded into the optimizer's grad_mul).  The reference gets the same effect
+    implicitly from DDP inside accelerator.backward (train_lora_dreambooth.py:744-757,877).  Device-agnostic:
+    RCCL ("nccl") on the GPUs, gloo in the CPU tests."""
+
+    def __init__(self, grads: torch.Tensor, numel: int, process_group=None):
+        self.grads, self.numel, self.pg = grads, numel, process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.early_range: Optional[Tuple[int, int]] = None
+        self._armed = False
+        self._pending = []
+
+    def arm(self):
+        """Call before each backward pass; launch_early() then fires at most once."""
+        self._armed = self.world > 1 and self.early_range is not None
+
+    def launch_early(self):
+        """Start reducing the early bucket (its gradients are final) while backward continues."""
+        if self._armed:
+            self._armed = False
+            a, b = self.early_range
+            self._pending.append(dist.all_reduce(self.grads[a:b], group=self.pg, async_op=True))
+
+    def finish(self):
+        """Reduce whatever has not been sent yet and wait for every bucket."""
+        if self.world == 1:
+            return
+        n = self.numel
+        if self._pending:
+            a, b = self.early_range
+            if a > 0:
+                self._pending.append(dist.all_reduce(self.grads[:a], group=self.pg, async_op=True))
+            if b < n:
+                self._pending.append(dist.all_reduce(self.grads[b:n], group=self.pg, async_op=True))
+        else:
+            self._pending.append(dist.all_reduce(self.grads[:n], group=self.pg, async_op=True))
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+        self._armed = False
+
+
+class LoraTrainer:
+    """One object per process (= per GPU).  `step()` runs one full training step and returns the loss tensor
+    (no host sync unless the caller reads it)."""
+
+    def __init__(self, unet: nn.Module, text_encoder: Optional[nn.Module] = None, lr=1e-4, lr_text=5e-6,
+                 weight_decay=1e-2, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0, loss_scale: Optional[float] = None,
+                 v_prediction=False, process_group=None):
+        self.unet, self.text_encoder = unet, text_encoder
+        models = [unet] + ([text_encoder] if text_encoder is not None and lora_layers(text_encoder) else [])
+        self.slab = LoraSlab(models)
+        groups = [{"range": self.slab.model_ranges[0], "lr": lr, "weight_decay": weight_decay}]
+        if len(models) > 1:
+            groups.append({"range": self.slab.model_ranges[1], "lr": lr_text, "weight_decay": weight_decay})
+        self.opt = FusedClipAdamW(self.slab, groups, betas, eps, max_grad_norm)
+        self.device = self.slab.params.device
+        self.dtype = next(p for p in unet.parameters() if p.dim() == 4).dtype  # conv weight dtype = compute dtype
+        self.loss_scale = float(loss_scale) if loss_scale is not None else (1024.0 if self.dtype == torch.float16 else 1.0)
+        self.v_prediction = v_prediction
+        self.sqrt_acp, self.sqrt_1macp = ddpm_tables(device=self.device)
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.exchange = SlabExchange(self.slab.grads, self.slab.numel, process_group)
+        if self.world > 1:
+            self._broadcast_initial_state()
+            self._install_bucket_hook()
+
+    # -- data parallel -------------------------------------------------------------------------
+    def _broadcast_initial_state(self):
+        """DDP construction broadcasts module state from rank 0 (train_lora_dreambooth.py:751-757); the frozen
+        base is loaded identically everywhere, so only the LoRA slab travels."""
+        dist.broadcast(self.slab.params, src=0, group=self.pg)
+
+    def _install_bucket_hook(self):
+        """Two buckets in backward-completion order.  Enumeration order is down, up, mid; backward finishes the
+        up blocks first, then mid, then the down blocks — so [up|mid] is a contiguous early bucket whose
+        all-reduce overlaps the rest of the backward pass."""
+        mid = getattr(self.unet, "mid_block", None)
+        ups = getattr(self.unet, "up_blocks", None)
+        if mid is None or ups is None:
+            return
+        a0, a1 = self.slab.range_of(ups)
+        b0, b1 = self.slab.range_of(mid)
+        if a1 != b0 or a1 <= a0:
+            return
+        self.exchange.early_range = (a0, b1)
+        mid.register_full_backward_hook(lambda module, gin, gout: self.exchange.launch_early())
+
+    # -- one step ---------------------------------------------------------------------------------
+    def step(self, latents, noise, timesteps, encoder_hidden_states, *, with_prior_preservation=False,
+             prior_loss_weight=1.0, mask=None):
+        """latents/noise fp32 [B,4,h,w] on the device, timesteps int64 [B], encoder_hidden_states [B,L,D]."""
+        self.slab.zero_grad()
+        noisy, target = nat.ddpm_add_noise(latents, noise, timesteps, self.sqrt_acp, self.sqrt_1macp, self.dtype,
+                                           self.v_prediction)
+        self.exchange.arm()
+        pred = self.unet(noisy, timesteps, encoder_hidden_states.to(self.dtype)).sample
+        rows = pred.shape[0]
+        n_inst, n_prior = (rows // 2, rows // 2) if with_prior_preservation else (rows, 0)
+        m = None
+        if mask is not None:
+            raw = mask.to(self.device).reshape(rows, 1, pred.shape[2] * 8, pred.shape[3] * 8).float().contiguous()
+            m = nat.lora_mask_prepare(raw, pred.shape[2], pred.shape[3])
+        pred_c = pred if pred.is_contiguous() else pred.contiguous()
+        loss, dpred = nat.ddpm_mse_fwd_bwd(pred_c, target, m, n_inst, n_prior, prior_loss_weight, self.loss_scale)
+        pred_c.backward(dpred)
+        self.exchange.finish()
+        self.opt.step(grad_mul=1.0 / (self.world * self.loss_scale))
+        return loss
+
+
+def flat_lora_state(model: nn.Module, targets=None) -> torch.Tensor:
+    """[up0, down0, up1, ...] flattened — the `.pt` file order."""
+    return torch.cat([t.detach().float().reshape(-1) for l in lora_layers(model)
+                      for t in (l.lora_up.weight, l.lora_down.weight)])

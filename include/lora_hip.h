@@ -108,11 +108,13 @@ int lora_mask_prepare(const float* mask_in, float* mask_out, int B, int Hin, int
                       void* stream);
 
 /*
- * weight_apply_lora — lora_diffusion/lora.py:410-424:   W ← W + (α·(B·A)).type(W.dtype)
- * In place on W[N,K] (dtype), A[r,K], B[N,r] fp32.
+ * weight_apply_lora — lora_diffusion/lora.py:410-424:   W ← W + α·(B @ A).type(W.dtype)
+ * In place on W[N,K] (dtype); A[r,K], B[N,r] passed as fp32.  The reference forms B @ A in the dtype the
+ * factors are held in (fp16 when they come from a `.pt` file): `factor_dtype` names it, and the product
+ * is rounded to it before the cast to W's dtype, the multiply by α and the add — op-by-op as the reference.
  */
 int lora_merge_weight(void* W, const float* A, const float* B, int K, int N, int r, float alpha,
-                      int dtype, void* stream);
+                      int dtype, int factor_dtype, void* stream);
 
 /* Out-of-place transpose+cast helper used to build the cached operands:
  * dst[cols,rows] (dst_dtype) = src[rows,cols] (src_dtype)ᵀ ; transpose=0 gives a plain cast. */

@@ -1,0 +1,49 @@
+"""The C-ABI library loads on a machine without a GPU and exports exactly what include/lora_hip.h declares."""
+import ctypes
+import os
+import re
+
+from diffusion_finetuning_amd import _native as nat
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "lora_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"^\s*(?:const\s+char\s*\*|int64_t|int)\s+(\w+)\s*\(", text, flags=re.M)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    declared = _declared_functions()
+    assert len(declared) >= 16 and "lora_linear_fwd" in declared and "ddpm_mse_fwd_bwd" in declared
+    handle = ctypes.CDLL(nat.library_path())
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in lora_hip.h but not exported"
+    assert sorted(nat.SIGNATURES) == declared  # the Python binding covers the whole header, nothing more
+
+
+def test_version_and_status_strings_without_gpu():
+    lib = nat.lib()
+    assert lib.lora_version() == nat.ABI_VERSION == 1
+    assert lib.lora_status_string(0) == b"ok"
+    assert b"rank" in lib.lora_status_string(-2).lower()
+    assert lib.lora_mse_workspace_bytes() >= 16 and lib.lora_sqnorm_workspace_bytes() >= 16
+
+
+def test_argument_validation_needs_no_gpu():
+    lib = nat.lib()
+    # null pointers / bad rank are rejected before any HIP call
+    assert lib.lora_linear_fwd(None, None, None, None, None, None, None, 4, 8, 8, 2, 1.0, 1, None) == -1
+    assert lib.lora_linear_fwd(None, None, None, None, None, None, None, 4, 8, 8, 9, 1.0, 1, None) == -2
+    assert lib.lora_linear_fwd(None, None, None, None, None, None, None, 4, 8, 8, 2, 1.0, 7, None) == -1
+    assert lib.lora_linear_bwd_params(None, None, None, None, None, None, 4, 8, 8, 0, 1.0, 1, None) == -2
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "diffusion_finetuning_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f

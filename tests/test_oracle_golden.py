@@ -1,0 +1,131 @@
+"""The CPU oracle must reproduce every vector the reference produced (tests/golden, made by oracle/make_golden.py)."""
+import json
+
+import torch
+
+from oracle import lora_oracle as orc
+
+TOL = 2e-6
+
+
+def test_operator_forward_backward(golden_operator, relerr):
+    t, meta = golden_operator
+    cases = [k for k in meta if k.startswith("c")]
+    assert len(cases) == 8
+    for c in cases:
+        cfg = json.loads(meta[c])
+        x, w, dy = t[f"{c}.x"].float(), t[f"{c}.w"].float(), t[f"{c}.dy"].float()
+        b = t[f"{c}.b"].float() if cfg["bias"] else None
+        down, up = t[f"{c}.down"], t[f"{c}.up"]
+        y = orc.lora_linear_forward(x, w, b, down, up, cfg["scale"])
+        dx, g_down, g_up = orc.lora_linear_backward(x, w, down, up, cfg["scale"], dy)
+        assert relerr(y, t[f"{c}.y"]) < TOL
+        assert relerr(dx, t[f"{c}.dx"]) < TOL
+        assert relerr(g_down, t[f"{c}.g_down"]) < TOL
+        assert relerr(g_up, t[f"{c}.g_up"]) < TOL
+
+
+def test_operator_module_matches_reference_init_and_error(golden_operator):
+    _, meta = golden_operator
+    torch.manual_seed(7)
+    layer = orc.LoraInjectedLinear(320, 320, False, 4)
+    init = json.loads(meta["init"])
+    assert abs(float(layer.lora_down.weight.std()) - init["down_std"]) < 1e-7  # same RNG stream, same init calls
+    assert float(layer.lora_up.weight.abs().max()) == init["up_absmax"] == 0.0
+    try:
+        orc.LoraInjectedLinear(8, 16, False, 9)
+        assert False
+    except ValueError as e:
+        assert str(e) == meta["rank_error"]
+
+
+def test_losses(golden_losses, relerr):
+    t, meta = golden_losses
+    for tag, fn in (("plain", lambda p, q: orc.mse_loss(p, q)),
+                    ("prior", lambda p, q: orc.prior_preservation_loss(p, q, float(meta["prior_loss_weight"])))):
+        pred = t[f"{tag}.pred"].float().requires_grad_(True)
+        loss = fn(pred, t[f"{tag}.target"].float())
+        loss.backward()
+        assert abs(loss.item() - t[f"{tag}.loss"].item()) < 1e-6
+        assert relerr(pred.grad, t[f"{tag}.dpred"]) < TOL
+    pred = t["masked.pred"].float().requires_grad_(True)
+    assert relerr(orc.prepare_mask(t["masked.raw_mask"], 8, 8), t["masked.mask"]) < 1e-7
+    loss = orc.masked_mse_loss(pred, t["masked.target"].float(), t["masked.raw_mask"])
+    loss.backward()
+    assert abs(loss.item() - t["masked.loss"].item()) < 1e-6
+    assert relerr(pred.grad, t["masked.dpred"]) < TOL
+
+
+def test_merge(golden_merge, relerr):
+    t, _ = golden_merge
+    for alpha in (0.5, 1.0, 1.2):
+        for dt, tag in ((torch.float32, "f32"), (torch.float16, "f16")):
+            q = orc.merge_weight(t["w_q"].to(dt), t["up0"], t["down0"], alpha)
+            o = orc.merge_weight(t["w_o"].to(dt), t["up1"], t["down1"], alpha)
+            assert q.dtype == dt
+            assert torch.equal(q.float(), t[f"merged_q.{tag}.a{alpha}"])
+            assert torch.equal(o.float(), t[f"merged_o.{tag}.a{alpha}"])
+
+
+def test_finder_order_and_injection(golden_structure, tiny_unet_factory):
+    unet = tiny_unet_factory()
+    got = [[path, m.in_features, m.out_features, m.bias is not None] for _, _, m, path in orc.find_targets(unet, orc.UNET_TARGETS)]
+    assert got == golden_structure["tiny_order"]
+    w0 = unet.down_blocks[0].attentions[0].transformer_blocks[0].attn1.to_q.weight
+    params, names = orc.inject(unet, r=4)
+    inj = golden_structure["tiny_inject"]
+    assert names == inj["names"]
+    assert 2 * len(names) == inj["n_generators"]
+    assert sum(p.numel() for p in params) == inj["n_lora_params"]
+    assert [k for k in unet.state_dict().keys() if "attn1.to_q" in k][:3] == inj["state_dict_keys"]
+    assert unet.down_blocks[0].attentions[0].transformer_blocks[0].attn1.to_q.linear.weight is w0  # shared Parameter
+    # a second pass finds nothing new: children of LoraInjectedLinear are excluded (lora.py:106-110)
+    assert orc.find_targets(unet, orc.UNET_TARGETS) == []
+
+
+def test_trajectory_10_steps(golden_trajectory, tiny_unet_factory, relerr):
+    """Row H: oracle loop (own clip + AdamW restatement) == reference loop with torch.optim.AdamW / clip_grad_norm_."""
+    t, meta = golden_trajectory
+    for tag in ("plain", "prior"):
+        cfg = json.loads(meta[tag])
+        unet = tiny_unet_factory(seed=cfg["unet_seed"])
+        params, _ = orc.inject(unet, r=4)
+        g = torch.Generator().manual_seed(cfg["warm_seed"])
+        with torch.no_grad():
+            for i, p in enumerate(params):
+                if i % 2 == 0:
+                    p.copy_(torch.randn(p.shape, generator=g) * cfg["warm_std"])
+        assert torch.equal(orc.flat_params(params), t[f"{tag}.init"])
+        losses = orc.train_steps(unet, params, cfg["steps"], cfg["batch"], cfg["latent_hw"], cfg["ctx_len"], cfg["ctx_dim"],
+                                 lr=cfg["lr"], with_prior=cfg["with_prior"])
+        assert relerr(torch.tensor(losses), t[f"{tag}.losses"]) < 1e-5
+        assert relerr(orc.flat_params(params), t[f"{tag}.final"]) < 1e-5
+
+
+def test_virtual_two_rank_equals_one_rank_double_batch(tiny_unet_factory, relerr):
+    """§8e parity: N ranks with batch B == 1 rank with batch N·B (mean of equal-sized means)."""
+    finals = []
+    for world, batch in ((1, 4), (2, 2)):
+        unet = tiny_unet_factory(seed=3)
+        params, _ = orc.inject(unet, r=4)
+        g = torch.Generator().manual_seed(11)
+        with torch.no_grad():
+            for i, p in enumerate(params):
+                if i % 2 == 0:
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+        orc.train_steps(unet, params, 3, batch, 8, 6, 32, lr=1e-3, world=world)
+        finals.append(orc.flat_params(params))
+    assert relerr(finals[1], finals[0]) < 1e-5
+
+
+def test_ddpm_schedule_properties():
+    acp = orc.ddpm_alphas_cumprod()
+    assert acp.shape == (1000,) and bool((acp[1:] < acp[:-1]).all())
+    assert abs(acp[0].item() - (1 - 0.00085)) < 1e-6
+    x0, eps = torch.randn(3, 4, 8, 8), torch.randn(3, 4, 8, 8)
+    t = torch.tensor([0, 500, 999])
+    noisy, vel = orc.add_noise(x0, eps, t, acp), orc.get_velocity(x0, eps, t, acp)
+    a, s = acp[t].sqrt().reshape(-1, 1, 1, 1), (1 - acp[t]).sqrt().reshape(-1, 1, 1, 1)
+    # (noisy, velocity) is a rotation of (x0, eps): invertible
+    assert torch.allclose(a * noisy - s * vel, x0, atol=1e-5)
+    assert torch.allclose(s * noisy + a * vel, eps, atol=1e-5)
