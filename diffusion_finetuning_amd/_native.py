@@ -14,8 +14,7 @@ _lib = None
 _lock = threading.Lock()
 
 ABI_VERSION = 1
-PROF_KINDS = 4
-PROF_KIND_NAMES = ("lora_linear_fwd", "lora_linear_bwd_input", "lora_linear_bwd_params", "ddpm_mse_fwd_bwd")
+PROF_KINDS = 10
 
 _DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
@@ -49,6 +48,7 @@ SIGNATURES = {
     "ddpm_add_noise": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
     "lora_prof_enable": (_i32, [_i32]),
     "lora_prof_collect": (_i32, [ctypes.POINTER(ProfTotals)]),
+    "lora_prof_kernel_name": (ctypes.c_char_p, [_i32]),
 }
 
 
@@ -253,7 +253,7 @@ def prof_collect():
     tot = ProfTotals()
     _check(lib().lora_prof_collect(ctypes.byref(tot)), "lora_prof_collect")
     return {
-        PROF_KIND_NAMES[k]: {"launches": int(tot.launches[k]), "ms": float(tot.ms[k]), "bytes": float(tot.bytes[k]),
-                             "flops": float(tot.flops[k])}
-        for k in range(PROF_KINDS)
+        lib().lora_prof_kernel_name(k).decode(): {"launches": int(tot.launches[k]), "ms": float(tot.ms[k]),
+                                                  "bytes": float(tot.bytes[k]), "flops": float(tot.flops[k])}
+        for k in range(PROF_KINDS) if tot.launches[k] > 0
     }

@@ -1,6 +1,7 @@
 // Shared device helpers for liblora_hip (gfx950 / CDNA4 only: wave64, MFMA, 160 KiB LDS).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/lora_hip.h"
@@ -41,9 +42,29 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// Launch-profiler hooks (prof.hip).  begin returns a slot (<0: profiling off).
-int lora_prof_begin(int kind, double bytes, double flops, hipStream_t stream);
-void lora_prof_end(int slot, hipStream_t stream);
+// Launch-profiler hooks (prof.hip).  An entry point declares the algorithmic work of its next launch with a
+// ProfWork object; LORA_LAUNCH attaches start/stop events to the dispatch itself (hipExtLaunchKernelGGL), so
+// the recorded time is the kernel's own duration, not the gap between host-side event records.
+enum ProfKernel {
+    PK_GEMM_128x128 = 0, PK_GEMM_128x64, PK_GEMM_64x64, PK_SKINNY_128, PK_SKINNY_64,
+    PK_GRAD_R4, PK_GRAD_R8, PK_GRAD_R16, PK_MSE, PK_OTHER, PK_COUNT
+};
+static_assert(PK_COUNT == LORA_PROF_KINDS, "lora_hip.h LORA_PROF_KINDS out of date");
+void lora_prof_set_work(double bytes, double flops);
+bool lora_prof_acquire(int kernel_id, hipEvent_t* e0, hipEvent_t* e1);
+struct ProfWork {
+    ProfWork(double bytes, double flops) { lora_prof_set_work(bytes, flops); }
+    ~ProfWork() { lora_prof_set_work(0.0, 0.0); }
+};
+
+#define LORA_LAUNCH(id, kern, grid, block, lds, stream, ...)                                     \
+    do {                                                                                          \
+        hipEvent_t e0_, e1_;                                                                      \
+        if (lora_prof_acquire(id, &e0_, &e1_))                                                    \
+            hipExtLaunchKernelGGL(kern, grid, block, lds, stream, e0_, e1_, 0, __VA_ARGS__);      \
+        else                                                                                      \
+            hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                      \
+    } while (0)
 
 #define LORA_LAUNCH_CHECK()                                   \
     do {                                                      \

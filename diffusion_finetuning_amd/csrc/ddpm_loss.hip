@@ -169,9 +169,9 @@ int launch_mse(MseParams p, hipStream_t s) {
     if (blocks > kMaxBlocks) blocks = kMaxBlocks;
     if (blocks < 1) blocks = 1;
     if (vec)
-        hipLaunchKernelGGL((ddpm_mse_kernel<T, V>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        LORA_LAUNCH(PK_MSE, (ddpm_mse_kernel<T, V>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     else
-        hipLaunchKernelGGL((ddpm_mse_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        LORA_LAUNCH(PK_MSE, (ddpm_mse_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     LORA_LAUNCH_CHECK();
     return LORA_OK;
 }
@@ -199,7 +199,7 @@ extern "C" int ddpm_mse_fwd_bwd(const void* pred, const void* target, const floa
     p.coef_prior = n_prior > 0 ? prior_weight / ((float)n_prior * (float)per_row) : 0.f;
     p.grad_scale = grad_scale;
     const double e = dtype == LORA_F32 ? 4.0 : 2.0;
-    const int slot = lora_prof_begin(3, e * (double)p.n_total * (dpred ? 3.0 : 2.0), 4.0 * (double)p.n_total, s);
+    ProfWork work(e * (double)p.n_total * (dpred ? 3.0 : 2.0), 4.0 * (double)p.n_total);
     int rc;
     switch (dtype) {
         case LORA_F32: rc = launch_mse<float>(p, s); break;
@@ -207,7 +207,6 @@ extern "C" int ddpm_mse_fwd_bwd(const void* pred, const void* target, const floa
         case LORA_BF16: rc = launch_mse<bf16_t>(p, s); break;
         default: rc = LORA_E_BADARG;
     }
-    lora_prof_end(slot, s);
     return rc;
 }
 

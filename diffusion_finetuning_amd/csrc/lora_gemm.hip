@@ -438,7 +438,9 @@ int launch_tile(GemmParams p, hipStream_t stream) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return LORA_E_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), lds, stream, p);
+    constexpr int prof_id = MAIN ? (BM == 128 && BN == 128 ? PK_GEMM_128x128 : (BM == 128 ? PK_GEMM_128x64 : PK_GEMM_64x64))
+                                 : (BM == 128 ? PK_SKINNY_128 : PK_SKINNY_64);
+    LORA_LAUNCH(prof_id, kern, dim3(p.tiles_m * p.tiles_n), dim3(256), lds, stream, p);
     LORA_LAUNCH_CHECK();
     return LORA_OK;
 }
@@ -523,8 +525,8 @@ extern "C" int lora_linear_fwd(const void* X, const void* W, const void* bias, c
                                float scale, int dtype, void* stream) {
     const int st = check_common(M, K, N, r, dtype);
     if (st != LORA_OK) return st;
+    if (M == 0) return LORA_OK;  // empty batch: nothing to do (pointers may be null)
     if (!X || !W || !A || !B || !Y || !T_out) return LORA_E_BADARG;
-    if (M == 0) return LORA_OK;
     GemmParams p{};
     p.Am = X; p.Bm = W; p.bias = bias;
     p.F = A; p.f_sr = K; p.f_sk = 1;   // F[j,k] = A[j,k]
@@ -533,11 +535,9 @@ extern "C" int lora_linear_fwd(const void* X, const void* W, const void* bias, c
     p.M = M; p.Kc = K; p.Nc = N; p.r = r; p.scale = scale;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const double e = esize(dtype);
-    const int slot = lora_prof_begin(0, e * ((double)M * K + (double)N * K + (double)M * N) + e * r * (K + N) + (bias ? e * N : 0.0),
-                                     2.0 * M * K * N + 2.0 * M * r * (double)(K + N), s);
-    const int rc = launch_gemm(p, true, dtype, s);
-    lora_prof_end(slot, s);
-    return rc;
+    ProfWork work(e * ((double)M * K + (double)N * K + (double)M * N) + e * r * (K + N) + (bias ? e * N : 0.0),
+                  2.0 * M * K * N + 2.0 * M * r * (double)(K + N));
+    return launch_gemm(p, true, dtype, s);
 }
 
 extern "C" int lora_linear_bwd_input(const void* dY, const void* Wt, const float* A, const float* B,
@@ -545,9 +545,9 @@ extern "C" int lora_linear_bwd_input(const void* dY, const void* Wt, const float
                                      int dtype, void* stream) {
     const int st = check_common(M, K, N, r, dtype);
     if (st != LORA_OK) return st;
+    if (M == 0) return LORA_OK;
     if (!dY || !A || !B || !U_out) return LORA_E_BADARG;
     if (dX && !Wt) return LORA_E_BADARG;
-    if (M == 0) return LORA_OK;
     GemmParams p{};
     p.Am = dY; p.Bm = Wt; p.bias = nullptr;
     p.F = B; p.f_sr = 1; p.f_sk = r;   // F[j,n] = B[n,j]
@@ -559,8 +559,6 @@ extern "C" int lora_linear_bwd_input(const void* dY, const void* Wt, const float
     const double bytes = dX ? e * ((double)M * N + (double)N * K + (double)M * K) + e * r * (K + N)
                             : e * (double)M * N + e * r * N;
     const double flops = dX ? 2.0 * M * K * N + 2.0 * M * r * (double)(K + N) : 2.0 * M * r * (double)N;
-    const int slot = lora_prof_begin(1, bytes, flops, s);
-    const int rc = launch_gemm(p, dX != nullptr, dtype, s);
-    lora_prof_end(slot, s);
-    return rc;
+    ProfWork work(bytes, flops);
+    return launch_gemm(p, dX != nullptr, dtype, s);
 }

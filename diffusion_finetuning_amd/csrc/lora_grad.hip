@@ -153,9 +153,9 @@ int launch_grad(GradParams p, hipStream_t stream) {
     const unsigned gy = (unsigned)((p.M + rpb - 1) / rpb);
     dim3 grid(max_strips, gy, 2);
     switch (rp) {
-        case 4: hipLaunchKernelGGL((lora_grad_kernel<T, 4>), grid, dim3(256), max_lds, stream, p); break;
-        case 8: hipLaunchKernelGGL((lora_grad_kernel<T, 8>), grid, dim3(256), max_lds, stream, p); break;
-        default: hipLaunchKernelGGL((lora_grad_kernel<T, 16>), grid, dim3(256), max_lds, stream, p); break;
+        case 4: LORA_LAUNCH(PK_GRAD_R4, (lora_grad_kernel<T, 4>), grid, dim3(256), max_lds, stream, p); break;
+        case 8: LORA_LAUNCH(PK_GRAD_R8, (lora_grad_kernel<T, 8>), grid, dim3(256), max_lds, stream, p); break;
+        default: LORA_LAUNCH(PK_GRAD_R16, (lora_grad_kernel<T, 16>), grid, dim3(256), max_lds, stream, p); break;
     }
     LORA_LAUNCH_CHECK();
     return LORA_OK;
@@ -168,16 +168,16 @@ extern "C" int lora_linear_bwd_params(const void* dY, const void* X, const float
                                       int dtype, void* stream) {
     if (M < 0 || K <= 0 || N <= 0) return LORA_E_BADARG;
     if (r < 1 || r > (K < N ? K : N)) return LORA_E_RANK;
-    if (!dY || !X || !T || !U || !gA || !gB) return LORA_E_BADARG;
     if (M == 0) return LORA_OK;
+    if (!dY || !X || !T || !U || !gA || !gB) return LORA_E_BADARG;
     GradParams p{};
     p.prob[0].S = dY; p.prob[0].P = T; p.prob[0].G = gB; p.prob[0].C = N; p.prob[0].out_kn = 0;
     p.prob[1].S = X;  p.prob[1].P = U; p.prob[1].G = gA; p.prob[1].C = K; p.prob[1].out_kn = 1;
     p.M = M; p.r = r; p.scale = scale;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const double e = dtype == LORA_F32 ? 4.0 : 2.0;
-    const int slot = lora_prof_begin(2, e * ((double)M * N + (double)M * K) + 4.0 * r * (double)(K + N) + 8.0 * M * r,
-                                     4.0 * M * r * (double)(K + N), s);
+    ProfWork work(e * ((double)M * N + (double)M * K) + 4.0 * r * (double)(K + N) + 8.0 * M * r,
+                  2.0 * M * r * (double)(K + N));
     int rc;
     switch (dtype) {
         case LORA_F32: rc = launch_grad<float>(p, s); break;
@@ -185,6 +185,5 @@ extern "C" int lora_linear_bwd_params(const void* dY, const void* X, const float
         case LORA_BF16: rc = launch_grad<bf16_t>(p, s); break;
         default: rc = LORA_E_BADARG;
     }
-    lora_prof_end(slot, s);
     return rc;
 }

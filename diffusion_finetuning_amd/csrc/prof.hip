@@ -1,6 +1,8 @@
-// Library identity + the optional launch profiler (HIP events on the caller's stream).
-// The profiler is measurement infrastructure for bench.py's `roofline` object: it is the only
-// mutable global state in the library, guarded by a mutex, and inert unless enabled.
+// Library identity + the optional launch profiler.
+// The profiler is measurement infrastructure for bench.py's `roofline` object: the only mutable global
+// state in the library, guarded by a mutex, and inert unless enabled.  Start/stop events are attached to
+// the kernel dispatch itself (hipExtLaunchKernelGGL in LORA_LAUNCH), so a record is the kernel's own
+// duration on the caller's stream — the same quantity rocprofv3 --kernel-trace reports.
 #include <mutex>
 #include <vector>
 
@@ -23,28 +25,33 @@ ProfState& prof() {
     static ProfState s;
     return s;
 }
+thread_local double tl_bytes = 0.0, tl_flops = 0.0;
+
+const char* const kKernelNames[LORA_PROF_KINDS] = {
+    "lora_gemm_kernel<*, 128, 128, true>", "lora_gemm_kernel<*, 128, 64, true>", "lora_gemm_kernel<*, 64, 64, true>",
+    "lora_gemm_kernel<*, 128, 64, false>", "lora_gemm_kernel<*, 64, 64, false>", "lora_grad_kernel<*, 4>",
+    "lora_grad_kernel<*, 8>",              "lora_grad_kernel<*, 16>",             "ddpm_mse_kernel",
+    "other"};
 
 }  // namespace
 
-int lora_prof_begin(int kind, double bytes, double flops, hipStream_t stream) {
-    ProfState& s = prof();
-    if (!s.on) return -1;
-    std::lock_guard<std::mutex> lk(s.mu);
-    if (!s.on || s.used >= (int)s.rec.size()) return -1;
-    const int slot = s.used++;
-    ProfRecord& r = s.rec[slot];
-    r.kind = kind;
-    r.bytes = bytes;
-    r.flops = flops;
-    (void)hipEventRecord(r.e0, stream);
-    return slot;
+void lora_prof_set_work(double bytes, double flops) {
+    tl_bytes = bytes;
+    tl_flops = flops;
 }
 
-void lora_prof_end(int slot, hipStream_t stream) {
-    if (slot < 0) return;
+bool lora_prof_acquire(int kernel_id, hipEvent_t* e0, hipEvent_t* e1) {
     ProfState& s = prof();
+    if (!s.on) return false;
     std::lock_guard<std::mutex> lk(s.mu);
-    if (slot < s.used) (void)hipEventRecord(s.rec[slot].e1, stream);
+    if (!s.on || s.used >= (int)s.rec.size()) return false;
+    ProfRecord& r = s.rec[s.used++];
+    r.kind = kernel_id;
+    r.bytes = tl_bytes;
+    r.flops = tl_flops;
+    *e0 = r.e0;
+    *e1 = r.e1;
+    return true;
 }
 
 extern "C" int lora_version(void) { return LORA_HIP_ABI_VERSION; }
@@ -59,6 +66,10 @@ extern "C" const char* lora_status_string(int status) {
         case LORA_E_UNSUPPORTED: return "unsupported combination";
         default: return "unknown status";
     }
+}
+
+extern "C" const char* lora_prof_kernel_name(int kind) {
+    return (kind >= 0 && kind < LORA_PROF_KINDS) ? kKernelNames[kind] : "";
 }
 
 extern "C" int lora_prof_enable(int capacity) {

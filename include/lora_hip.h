@@ -153,12 +153,14 @@ int ddpm_add_noise(const float* x0, const float* eps, const int64_t* t, const fl
                    int v_prediction, int dtype, void* stream);
 
 /*
- * Launch profiler (measurement only; off by default).  When enabled every lora_linear_* call
- * brackets its kernel with HIP events on the caller's stream and records (kind, algorithmic
- * bytes, algorithmic flops).  lora_prof_collect synchronises the recorded events and returns
- * per-kind totals.  kind: 0 = fwd, 1 = bwd_input, 2 = bwd_params, 3 = mse.
+ * Launch profiler (measurement only; off by default).  When enabled, the hot-path kernels are launched
+ * with start/stop events attached to the dispatch itself, so each record is that kernel's own duration on
+ * the caller's stream, together with the ALGORITHMIC bytes and flops of the call (formulas: DESIGN.md §5).
+ * Records are grouped per kernel instantiation (the names rocprofv3 shows); lora_prof_kernel_name(i)
+ * returns a substring of that name.  lora_prof_collect waits for the recorded events, returns the totals
+ * and resets the recording.
  */
-#define LORA_PROF_KINDS 4
+#define LORA_PROF_KINDS 10
 typedef struct lora_prof_totals {
     int64_t launches[LORA_PROF_KINDS];
     double ms[LORA_PROF_KINDS];
@@ -166,7 +168,8 @@ typedef struct lora_prof_totals {
     double flops[LORA_PROF_KINDS];
 } lora_prof_totals;
 int lora_prof_enable(int capacity /* max recorded launches; 0 disables and frees */);
-int lora_prof_collect(lora_prof_totals* out /* also resets the recording */);
+int lora_prof_collect(lora_prof_totals* out);
+const char* lora_prof_kernel_name(int kind);
 
 #ifdef __cplusplus
 }
