@@ -72,14 +72,32 @@ def synthetic_steps(n_steps, batch, latent, rank, world, device):
     return out
 
 
+def usable_cpus() -> int:
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU box shows 256
+    logical CPUs but grants a 16-CPU share; oversubscribing the quota stalls every OpenMP region)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def cpu_baseline(latent, rank_r, steps):
     """The CPU oracle (a restatement of the reference path, kind="port") timed on this box's host cores on a
     bounded sample of the same workload: batch 1 at the same resolution, fp32 (the reference's CPU path)."""
     from diffusion_finetuning_amd.unet import UNet2DConditionModel, sd15_config
     from oracle import lora_oracle as orc
 
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     torch.set_num_threads(cores)
+    log(f"cpu_baseline: oracle on {cores} host threads, {steps} timed steps + 1 warm-up")
     torch.manual_seed(0)
     unet = UNet2DConditionModel(sd15_config())
     unet.requires_grad_(False)
@@ -105,6 +123,7 @@ def main():
         args.gpus = world
     import torch.distributed as dist
 
+    torch.set_num_threads(max(1, usable_cpus() // max(1, world if world <= 8 else 8)))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -125,10 +144,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if rank == 0:
+        log(f"model + {len(data)} synthetic batches resident on {torch.cuda.get_device_name(local_rank)}; warm-up")
     losses = []
     for i in range(args.warmup):
         losses.append(trainer.step(*data[i]))
     barrier()
+    if rank == 0:
+        log(f"timing {args.steps} steps")
     profiled = rank == 0 and not args.no_prof
     if profiled:
         nat.prof_enable(args.steps * 600)
@@ -145,6 +168,8 @@ def main():
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    if rank == 0:
+        log(f"timed region done: {1e3 * elapsed / args.steps:.2f} ms/step")
     final_loss = float(losses[-1].item())
     overflow = trainer.opt.overflowed()
 
