@@ -34,9 +34,12 @@ class ProfTotals(ctypes.Structure):
 SIGNATURES = {
     "lora_version": (_i32, []),
     "lora_status_string": (ctypes.c_char_p, [_i32]),
-    "lora_linear_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
-    "lora_linear_bwd_input": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
-    "lora_linear_bwd_params": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "lora_pack_factors": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "lora_pack_factors_batched": (_i32, [_vp, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "lora_linear_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "lora_linear_bwd_input": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "lora_linear_bwd_params": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "lora_reduce_partials": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp]),
     "ddpm_mse_fwd_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i64, _i64, _f32, _f32, _vp, _vp, _vp, _i32, _vp]),
     "lora_mse_workspace_bytes": (_i64, []),
     "lora_mask_prepare": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -115,46 +118,101 @@ def _require_device(*tensors) -> None:
             )
 
 
-def lora_linear_fwd(x2, w, bias, a, b, scale: float):
-    """x2 [M,K], w [N,K], bias [N]|None (dtype of x2); a [r,K], b [N,r] fp32. Returns (y [M,N], T [M,r] fp32)."""
-    _require_device(x2, w, bias, a, b)
+def lora_pack_factors(a, b, dtype: torch.dtype):
+    """a [r,K], b [N,r] fp32 → (A16 [16,K], Bt16 [16,N]) in `dtype`; (None, None) for r > 16."""
+    _require_device(a, b)
+    r, K = a.shape
+    N = b.shape[0]
+    if r > 16:
+        return None, None
+    a16 = torch.empty((16, K), dtype=dtype, device=a.device)
+    bt16 = torch.empty((16, N), dtype=dtype, device=a.device)
+    _check(lib().lora_pack_factors(_ptr(a), _ptr(b), _ptr(a16), _ptr(bt16), K, N, r, dtype_code(dtype), _stream(a)),
+           "lora_pack_factors")
+    return a16, bt16
+
+
+def lora_pack_factors_batched(table, n_layers: int, max_len: int, params, packed) -> None:
+    _require_device(table, params, packed)
+    _check(lib().lora_pack_factors_batched(_ptr(table), n_layers, max_len, _ptr(params), _ptr(packed),
+                                           dtype_code(packed.dtype), _stream(params)), "lora_pack_factors_batched")
+
+
+def lora_linear_fwd(x2, w, bias, a, b, scale: float, a16=None):
+    """x2 [M,K], w [N,K], bias [N]|None (dtype of x2); a [r,K], b [N,r] fp32 masters; a16 packed A
+    (made here when not given). Returns (y [M,N], T [M,r] fp32)."""
+    _require_device(x2, w, bias, a, b, a16)
     M, K = x2.shape
     N, r = b.shape
+    if a16 is None and r <= 16:
+        a16, _ = lora_pack_factors(a, b, x2.dtype)
     y = torch.empty((M, N), dtype=x2.dtype, device=x2.device)
     t = torch.empty((M, r), dtype=torch.float32, device=x2.device)
     _check(
-        lib().lora_linear_fwd(_ptr(x2), _ptr(w), _ptr(bias), _ptr(a), _ptr(b), _ptr(y), _ptr(t), M, K, N, r,
-                              float(scale), dtype_code(x2.dtype), _stream(x2)),
+        lib().lora_linear_fwd(_ptr(x2), _ptr(w), _ptr(bias), _ptr(a), _ptr(b), _ptr(a16), _ptr(y), _ptr(t), M, K, N,
+                              r, float(scale), dtype_code(x2.dtype), _stream(x2)),
         "lora_linear_fwd",
     )
     return y, t
 
 
-def lora_linear_bwd_input(dy2, wt, a, b, scale: float, need_dx: bool):
-    """dy2 [M,N]; wt [K,N] (= Wᵀ) or None when need_dx is False. Returns (dx [M,K]|None, U [M,r] fp32)."""
-    _require_device(dy2, wt, a, b)
+def lora_linear_bwd_input(dy2, wt, a, b, scale: float, need_dx: bool, bt16=None):
+    """dy2 [M,N]; wt [K,N] (= Wᵀ) or None when need_dx is False; bt16 packed Bᵀ (made here when not given).
+    Returns (dx [M,K]|None, U [M,r] fp32)."""
+    _require_device(dy2, wt, a, b, bt16)
     M, N = dy2.shape
     r, K = a.shape
+    if bt16 is None and r <= 16:
+        _, bt16 = lora_pack_factors(a, b, dy2.dtype)
     dx = torch.empty((M, K), dtype=dy2.dtype, device=dy2.device) if need_dx else None
     u = torch.empty((M, r), dtype=torch.float32, device=dy2.device)
     _check(
-        lib().lora_linear_bwd_input(_ptr(dy2), _ptr(wt), _ptr(a), _ptr(b), _ptr(dx), _ptr(u), M, K, N, r,
+        lib().lora_linear_bwd_input(_ptr(dy2), _ptr(wt), _ptr(a), _ptr(b), _ptr(bt16), _ptr(dx), _ptr(u), M, K, N, r,
                                     float(scale), dtype_code(dy2.dtype), _stream(dy2)),
         "lora_linear_bwd_input",
     )
     return dx, u
 
 
+def grad_blocks_for(M: int) -> int:
+    """Row blocks for the factor-gradient kernel when the caller has no fixed layout (plain autograd mode)."""
+    return max(1, min(128, (M + 15) // 16))
+
+
+def lora_linear_bwd_params_partial(dy2, x2, t, u, ga_part, gb_part, part_stride: int, n_blocks: int, scale: float):
+    """Stores per-row-block partial sums: block b at ga_part + b·part_stride ([r,K]) / gb_part + b·part_stride ([N,r])."""
+    _require_device(dy2, x2, t, u, ga_part, gb_part)
+    M, N = dy2.shape
+    K = x2.shape[1]
+    r = t.shape[1]
+    _check(
+        lib().lora_linear_bwd_params(_ptr(dy2), _ptr(x2), _ptr(t), _ptr(u), _ptr(ga_part), _ptr(gb_part),
+                                     int(part_stride), int(n_blocks), M, K, N, r, float(scale),
+                                     dtype_code(dy2.dtype), _stream(dy2)),
+        "lora_linear_bwd_params",
+    )
+
+
+def lora_reduce_partials(partials, part_stride: int, n_blocks: int, grads, n: int, accumulate: bool) -> None:
+    _require_device(partials, grads)
+    _check(lib().lora_reduce_partials(_ptr(partials), int(part_stride), int(n_blocks), _ptr(grads), int(n),
+                                      int(accumulate), _stream(grads)), "lora_reduce_partials")
+
+
 def lora_linear_bwd_params(dy2, x2, t, u, ga, gb, scale: float):
-    """Accumulates into ga [r,K], gb [N,r] (fp32, caller-zeroed)."""
+    """Accumulates into ga [r,K], gb [N,r] (fp32): partial sums per row block + ordered reduction."""
     _require_device(dy2, x2, t, u, ga, gb)
     M, N = dy2.shape
     r, K = ga.shape
-    _check(
-        lib().lora_linear_bwd_params(_ptr(dy2), _ptr(x2), _ptr(t), _ptr(u), _ptr(ga), _ptr(gb), M, K, N, r,
-                                     float(scale), dtype_code(dy2.dtype), _stream(dy2)),
-        "lora_linear_bwd_params",
-    )
+    nb = grad_blocks_for(M)
+    size = r * (K + N)
+    stride = (size + 3) // 4 * 4
+    ws = torch.empty((nb + 1, stride), dtype=torch.float32, device=dy2.device)
+    lora_linear_bwd_params_partial(dy2, x2, t, u, ws[0], ws[0, r * K:], stride, nb, scale)
+    out = ws[nb]
+    lora_reduce_partials(ws, stride, nb, out, size, False)
+    ga += out[: r * K].view(r, K)
+    gb += out[r * K: size].view(N, r)
 
 
 _ws_cache = {}

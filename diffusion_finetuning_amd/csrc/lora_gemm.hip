@@ -7,20 +7,26 @@
 //   C[M,Nc] = Am[M,Kc]·Bm[Nc,Kc]ᵀ + bias + s·P·Qᵀ ,   P[M,r] = Am·Fᵀ  (stored unscaled)
 // with (Am,Bm,F,Q) = (X, W, A, B) forward and (dY, Wᵀ, Bᵀ, Aᵀ) backward.  Both big operands are
 // contraction-contiguous ("NT" GEMM), which is why the frozen weight is cached in both
-// orientations.
+// orientations.  F arrives PACKED: [16, Kc] in the compute dtype, rows ≥ r zero
+// (lora_pack_factors), so it is staged exactly like an operand tile.
 //
 // Structure per 256-thread workgroup (4 waves as 2×2), BM×BN output tile, 128-byte K-steps:
-//   - register-staged global→LDS copies (16 B per lane, XOR-swizzled 16-B chunks), the loads of
-//     K-step t+1 in flight while step t is multiplied;
+//   - PIPE main loop: a 3-stage LDS ring filled by LDS-DMA (global_load_lds, 16 B per lane, no VGPR
+//     staging), two K-steps in flight behind a COUNTED s_waitcnt vmcnt and one raw s_barrier per step.
+//     The XOR swizzle of the 16-B chunks is applied to the per-lane SOURCE address (the DMA writes LDS in
+//     lane order) and again on the fragment reads, which are then bank-conflict-free ds_read_b128.
+//   - fallback main loop (contraction not a multiple of the K-step): register-staged, 2 barriers per step.
 //   - base contraction on MFMA 16x16x32 (f16/bf16) or 16x16x4 (f32, exact);
-//   - the rank-r factor F rides along as a 16-row LDS tile: the X fragments already in VGPRs are
-//     multiplied with it (one extra MFMA per row fragment, K-steps split between the two
-//     column waves), so T costs no extra HBM or LDS traffic for X;
-//   - epilogue: the two partial P tiles are summed through LDS, P is written once, and
-//     s·P·Qᵀ is added to the accumulators as ONE extra MFMA K-step: for 16-bit types the 32-wide
-//     step carries [hi(sP) | lo(sP)] × [Q | Q], keeping P at ~fp32 precision;
+//   - the rank-r factor rides along as a 16-row tile: the X fragments already in VGPRs are multiplied
+//     with it (one extra MFMA per row fragment, K-steps split between the two column waves), so T
+//     costs no extra HBM or LDS traffic for X;
+//   - epilogue: the two partial P tiles are summed through LDS, P is written once, and s·P·Qᵀ is added
+//     to the accumulators as ONE extra MFMA K-step: for 16-bit types the 32-wide step carries
+//     [hi(sP) | lo(sP)] × [Q | Q], keeping P at ~fp32 precision;
 //   - bias is added in fp32, the tile is transposed through LDS and stored as whole 16-B row chunks.
 // Workgroups are dealt to XCDs so that the column tiles of one row panel share an L2.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -29,8 +35,7 @@ struct GemmParams {
     const void* Am;
     const void* Bm;
     const void* bias;
-    const float* F;
-    int64_t f_sr, f_sk;  // F[j,k]  at F[j*f_sr + k*f_sk]
+    const void* Fp;  // packed factor [16, Kc] (dtype T)
     const float* Q;
     int64_t q_sn, q_sj;  // Q[n,j]  at Q[n*q_sn + j*q_sj]
     void* C;
@@ -43,9 +48,15 @@ struct GemmParams {
 
 constexpr int kRowBytes = 128;  // one K-step of one tile row
 constexpr int kRP = 16;         // rank padded to one MFMA fragment
+constexpr int kStages = 3;      // LDS ring depth of the PIPE loop
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * kRowBytes + ((chunk ^ (row & 7)) << 4);
+}
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc),
+                                     (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0);
 }
 
 template <typename T> struct Mfma;
@@ -62,18 +73,23 @@ template <> struct Mfma<bf16_t> {
     }
 };
 
-template <int BM, int BN, typename T> constexpr int gemm_lds_bytes(bool main_part) {
-    constexpr int tiles = (BM + BN) * kRowBytes;
-    constexpr int sf = kRP * kRowBytes;
-    constexpr int sq = BN * kRP * (int)sizeof(T);
+// One stage of the ring / the single staging buffer: A rows, B rows, 32 factor rows (two identical
+// 16-row copies so that every wave issues the same number of DMA loads per stage).
+template <int BM, int BN, bool MAIN> constexpr int stage_bytes() {
+    return (BM + (MAIN ? BN : 0) + 2 * kRP) * kRowBytes;
+}
+template <int BM, int BN, typename T, bool MAIN, bool PIPE> constexpr int gemm_lds_bytes() {
+    constexpr int ring = (PIPE ? kStages : 1) * stage_bytes<BM, BN, MAIN>();
+    constexpr int sq = MAIN ? BN * kRP * (int)sizeof(T) : 0;
     constexpr int ep = sizeof(T) == 4 ? 2 : 1;
-    constexpr int sc = (BM / ep) * (BN * (int)sizeof(T) + 16);
-    const int a = main_part ? tiles + sf + sq : BM * kRowBytes + sf;
-    const int b = main_part ? sc : 0;
+    constexpr int sc = MAIN ? (BM / ep) * (BN * (int)sizeof(T) + 16) : 0;
+    constexpr int sp = 2 * BM * kRP * 4;
+    constexpr int a = ring + sq;
+    constexpr int b = sc > sp ? sc : sp;
     return a > b ? a : b;
 }
 
-template <typename T, int BM, int BN, bool MAIN>
+template <typename T, int BM, int BN, bool MAIN, bool PIPE>
 __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
     constexpr int VEC = ElemTraits<T>::kVec;
     constexpr int BK = kRowBytes / (int)sizeof(T);
@@ -82,13 +98,13 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
     constexpr int PA = BM / 32;  // staging passes (32 rows per pass)
     constexpr int PB = BN / 32;
     constexpr bool F32 = sizeof(T) == 4;
+    constexpr int STAGE = stage_bytes<BM, BN, MAIN>();
+    constexpr int OFF_B = BM * kRowBytes;
+    constexpr int OFF_F = (BM + (MAIN ? BN : 0)) * kRowBytes;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sA = smem;
-    char* sB = smem + BM * kRowBytes;
-    char* sF = MAIN ? sB + BN * kRowBytes : sB;
-    char* sQ = sF + kRP * kRowBytes;
-    float* sP = reinterpret_cast<float*>(smem);  // epilogue overlay on sA: [2][BM][16]
+    char* sQ = smem + (PIPE ? kStages : 1) * STAGE;
+    float* sP = reinterpret_cast<float*>(smem);  // epilogue overlay: [2][BM][16]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -115,8 +131,9 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
 
     const T* Ag = static_cast<const T*>(p.Am);
     const T* Bg = static_cast<const T*>(p.Bm);
+    const T* Fg = static_cast<const T*>(p.Fp);
 
-    // ---- staging state -------------------------------------------------------------------
+    // ---- staging addresses: thread = (row ld_row (+32·pass), 16-B chunk ld_chunk) ------------
     const int ld_chunk = tid & 7;
     const int ld_row = tid >> 3;
     const T* a_ptr[PA];
@@ -124,76 +141,28 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
         int64_t m = m0 + ld_row + 32 * i;
-        if (m > p.M - 1) m = p.M - 1;
-        a_ptr[i] = Ag + m * p.Kc + ld_chunk * VEC;
+        if (m > p.M - 1) m = p.M - 1;  // clamp: rows past M are loaded from a valid row, never stored
+        a_ptr[i] = Ag + m * p.Kc;
     }
     if constexpr (MAIN) {
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
             int n = n0 + ld_row + 32 * i;
             if (n > p.Nc - 1) n = p.Nc - 1;
-            b_ptr[i] = Bg + (int64_t)n * p.Kc + ld_chunk * VEC;
+            b_ptr[i] = Bg + (int64_t)n * p.Kc;
         }
     }
-    const int f_row = tid >> 3;  // valid for tid < 128
-    const bool f_thread = tid < kRP * 8;
-
-    Chunk<T> ra[PA];
-    Chunk<T> rb[MAIN ? PB : 1];
-    Chunk<T> rf;
-
-    auto load_step = [&](int k0) {
-        const bool kin = (k0 + ld_chunk * VEC) < p.Kc;
-#pragma unroll
-        for (int i = 0; i < PA; ++i) {
-            if (kin) {
-                ra[i] = *reinterpret_cast<const Chunk<T>*>(a_ptr[i] + k0);
-            } else {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) ra[i].v[e] = from_f32<T>(0.f);
-            }
-        }
-        if constexpr (MAIN) {
-#pragma unroll
-            for (int i = 0; i < PB; ++i) {
-                if (kin) {
-                    rb[i] = *reinterpret_cast<const Chunk<T>*>(b_ptr[i] + k0);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) rb[i].v[e] = from_f32<T>(0.f);
-                }
-            }
-        }
-        if (f_thread) {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const int k = k0 + ld_chunk * VEC + e;
-                float v = 0.f;
-                if (f_row < p.r && k < p.Kc) v = p.F[f_row * p.f_sr + k * p.f_sk];
-                rf.v[e] = from_f32<T>(v);
-            }
-        }
-    };
-    auto store_step = [&]() {
-#pragma unroll
-        for (int i = 0; i < PA; ++i)
-            *reinterpret_cast<Chunk<T>*>(sA + lds_off(ld_row + 32 * i, ld_chunk)) = ra[i];
-        if constexpr (MAIN) {
-#pragma unroll
-            for (int i = 0; i < PB; ++i)
-                *reinterpret_cast<Chunk<T>*>(sB + lds_off(ld_row + 32 * i, ld_chunk)) = rb[i];
-        }
-        if (f_thread) *reinterpret_cast<Chunk<T>*>(sF + lds_off(f_row, ld_chunk)) = rf;
-    };
+    const T* f_ptr = Fg + (int64_t)(ld_row & 15) * p.Kc;
 
     // ---- Q tile (epilogue factor), staged once -------------------------------------------
     if constexpr (MAIN) {
         T* q = reinterpret_cast<T*>(sQ);
         for (int idx = tid; idx < BN * kRP; idx += 256) {
             const int n = idx >> 4, j = idx & 15;
-            float v = 0.f;
-            if (j < p.r && n0 + n < p.Nc) v = p.Q[(int64_t)(n0 + n) * p.q_sn + j * p.q_sj];
-            q[idx] = from_f32<T>(v);
+            const int nn = n0 + n < p.Nc ? n0 + n : p.Nc - 1;
+            const int jj = j < p.r ? j : p.r - 1;
+            const float v = p.Q[(int64_t)nn * p.q_sn + jj * p.q_sj];  // unconditional, clamped
+            q[idx] = from_f32<T>((j < p.r && n0 + n < p.Nc) ? v : 0.f);
         }
     }
 
@@ -206,14 +175,11 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) pacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (p.Kc + BK - 1) / BK;
-    load_step(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt > 0) __syncthreads();
-        store_step();
-        __syncthreads();
-        if (kt + 1 < nk) load_step((kt + 1) * BK);
-
+    // ---- one K-step of MFMA work out of a staged buffer ------------------------------------
+    auto compute = [&](const char* st) {
+        const char* sA = st;
+        const char* sB = st + OFF_B;
+        const char* sF = st + OFF_F;
         if constexpr (!F32) {
             using Frag = typename Mfma<T>::Frag;
 #pragma unroll
@@ -222,8 +188,7 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
                 Frag af[MI];
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
-                    af[mi] = *reinterpret_cast<const Frag*>(
-                        sA + lds_off(wm * (BM / 2) + mi * 16 + l15, chunk));
+                    af[mi] = *reinterpret_cast<const Frag*>(sA + lds_off(wm * (BM / 2) + mi * 16 + l15, chunk));
                 if (ks == wn) {
                     const Frag ff = *reinterpret_cast<const Frag*>(sF + lds_off(l15, chunk));
 #pragma unroll
@@ -233,13 +198,11 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
                     Frag bf[NI];
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
-                        bf[ni] = *reinterpret_cast<const Frag*>(
-                            sB + lds_off(wn * (BN / 2) + ni * 16 + l15, chunk));
+                        bf[ni] = *reinterpret_cast<const Frag*>(sB + lds_off(wn * (BN / 2) + ni * 16 + l15, chunk));
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                        for (int ni = 0; ni < NI; ++ni)
-                            acc[mi][ni] = Mfma<T>::run(af[mi], bf[ni], acc[mi][ni]);
+                        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = Mfma<T>::run(af[mi], bf[ni], acc[mi][ni]);
                 }
             }
         } else {
@@ -251,33 +214,114 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
                 f32x4 af[MI];
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
-                    af[mi] = *reinterpret_cast<const f32x4*>(
-                        sA + lds_off(wm * (BM / 2) + mi * 16 + l15, chunk));
+                    af[mi] = *reinterpret_cast<const f32x4*>(sA + lds_off(wm * (BM / 2) + mi * 16 + l15, chunk));
                 if (h == wn) {
                     const f32x4 ff = *reinterpret_cast<const f32x4*>(sF + lds_off(l15, chunk));
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
                         for (int mi = 0; mi < MI; ++mi)
-                            pacc[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi][e], ff[e],
-                                                                            pacc[mi], 0, 0, 0);
+                            pacc[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi][e], ff[e], pacc[mi], 0, 0, 0);
                 }
                 if constexpr (MAIN) {
                     f32x4 bf[NI];
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
-                        bf[ni] = *reinterpret_cast<const f32x4*>(
-                            sB + lds_off(wn * (BN / 2) + ni * 16 + l15, chunk));
+                        bf[ni] = *reinterpret_cast<const f32x4*>(sB + lds_off(wn * (BN / 2) + ni * 16 + l15, chunk));
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
                         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                             for (int ni = 0; ni < NI; ++ni)
-                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                    af[mi][e], bf[ni][e], acc[mi][ni], 0, 0, 0);
+                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi][e], bf[ni][e],
+                                                                                  acc[mi][ni], 0, 0, 0);
                 }
             }
+        }
+    };
+
+    const int nk = (p.Kc + BK - 1) / BK;
+    if constexpr (PIPE) {
+        // ---- LDS-DMA ring.  Lane (row, physical chunk c') fetches logical chunk c' ^ (row & 7): the DMA
+        // writes lane-linearly, so the swizzle lives on the source address and on the fragment reads.
+        constexpr int L = PA + (MAIN ? PB : 0) + 1;  // DMA loads per lane per stage
+        const int src_off = (ld_chunk ^ (ld_row & 7)) * VEC;
+        const int wave_rows = wave * 8 * kRowBytes;
+        auto issue = [&](int kt, int buf) {
+            char* st = smem + buf * STAGE + wave_rows;
+            const int k0 = kt * BK + src_off;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) glds16(a_ptr[i] + k0, st + 32 * i * kRowBytes);
+            if constexpr (MAIN) {
+#pragma unroll
+                for (int i = 0; i < PB; ++i) glds16(b_ptr[i] + k0, st + OFF_B + 32 * i * kRowBytes);
+            }
+            glds16(f_ptr + k0, st + OFF_F);
+        };
+        issue(0, 0);
+        if (nk > 1) issue(1, 1);
+        int buf = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            // stage kt landed for this wave once at most the L loads of stage kt+1 are outstanding
+            if (kt + 1 < nk) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();  // every wave's part of stage kt is in; stage kt-1 is fully read
+            if (kt + 2 < nk) issue(kt + 2, buf >= 1 ? buf - 1 : kStages - 1);  // refill the buffer read last step
+            compute(smem + buf * STAGE);
+            buf = buf + 1 == kStages ? 0 : buf + 1;
+        }
+    } else {
+        // ---- register-staged fallback (ragged contraction): unconditional clamped loads, zero on write ----
+        Chunk<T> ra[PA];
+        Chunk<T> rb[MAIN ? PB : 1];
+        Chunk<T> rfc;
+        int staged_k = 0;
+        auto load_step = [&](int k0) {
+            const int kc = k0 + ld_chunk * VEC;
+            const int kld = kc < p.Kc ? kc : p.Kc - VEC;  // Kc % VEC == 0 on this path
+            staged_k = kc;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) ra[i] = *reinterpret_cast<const Chunk<T>*>(a_ptr[i] + kld);
+            if constexpr (MAIN) {
+#pragma unroll
+                for (int i = 0; i < PB; ++i) rb[i] = *reinterpret_cast<const Chunk<T>*>(b_ptr[i] + kld);
+            }
+            rfc = *reinterpret_cast<const Chunk<T>*>(f_ptr + kld);
+        };
+        auto store_step = [&]() {
+            if (staged_k >= p.Kc) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+#pragma unroll
+                    for (int i = 0; i < PA; ++i) ra[i].v[e] = from_f32<T>(0.f);
+                    if constexpr (MAIN) {
+#pragma unroll
+                        for (int i = 0; i < PB; ++i) rb[i].v[e] = from_f32<T>(0.f);
+                    }
+                    rfc.v[e] = from_f32<T>(0.f);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < PA; ++i)
+                *reinterpret_cast<Chunk<T>*>(smem + lds_off(ld_row + 32 * i, ld_chunk)) = ra[i];
+            if constexpr (MAIN) {
+#pragma unroll
+                for (int i = 0; i < PB; ++i)
+                    *reinterpret_cast<Chunk<T>*>(smem + OFF_B + lds_off(ld_row + 32 * i, ld_chunk)) = rb[i];
+            }
+            *reinterpret_cast<Chunk<T>*>(smem + OFF_F + lds_off(ld_row, ld_chunk)) = rfc;
+        };
+        load_step(0);
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt > 0) __syncthreads();
+            store_step();
+            __syncthreads();
+            if (kt + 1 < nk) load_step((kt + 1) * BK);
+            compute(smem);
         }
     }
 
@@ -298,8 +342,7 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int j = half * 8 + e;
-                if (j < p.r)
-                    p.P[(m0 + row) * p.r + j] = sP[row * kRP + j] + sP[(BM + row) * kRP + j];
+                if (j < p.r) p.P[(m0 + row) * p.r + j] = sP[row * kRP + j] + sP[(BM + row) * kRP + j];
             }
         }
     }
@@ -320,8 +363,7 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
                 Frag pf;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float v =
-                        (sP[row * kRP + j0 + e] + sP[(BM + row) * kRP + j0 + e]) * p.scale;
+                    const float v = (sP[row * kRP + j0 + e] + sP[(BM + row) * kRP + j0 + e]) * p.scale;
                     const T hi = from_f32<T>(v);
                     const T lo = from_f32<T>(v - to_f32<T>(hi));
                     pf[e] = lq < 2 ? hi : lo;
@@ -343,8 +385,7 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
                     const float pv = (sP[row * kRP + j] + sP[(BM + row) * kRP + j]) * p.scale;
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] =
-                            __builtin_amdgcn_mfma_f32_16x16x4f32(pv, qv[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, qv[ni], acc[mi][ni], 0, 0, 0);
                 }
             }
         }
@@ -397,9 +438,23 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
     }
 }
 
-// Shape-agnostic path (unaligned sizes or r > 16): correct, not fast.
+// Shape-agnostic path (unaligned sizes or r > 16): correct, not fast.  F/Q read as fp32 masters.
+struct GenericParams {
+    const void* Am;
+    const void* Bm;
+    const void* bias;
+    const float* F;
+    int64_t f_sr, f_sk;
+    const float* Q;
+    int64_t q_sn, q_sj;
+    void* C;
+    float* P;
+    int64_t M;
+    int Kc, Nc, r;
+    float scale;
+};
 template <typename T>
-__global__ void lora_skinny_generic_kernel(GemmParams p) {
+__global__ void lora_skinny_generic_kernel(GenericParams p) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= p.M * p.r) return;
     const int64_t m = idx / p.r;
@@ -410,7 +465,7 @@ __global__ void lora_skinny_generic_kernel(GemmParams p) {
     p.P[idx] = s;
 }
 template <typename T>
-__global__ void lora_gemm_generic_kernel(GemmParams p) {
+__global__ void lora_gemm_generic_kernel(GenericParams p) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= p.M * p.Nc) return;
     const int64_t m = idx / p.Nc;
@@ -427,16 +482,52 @@ __global__ void lora_gemm_generic_kernel(GemmParams p) {
     static_cast<T*>(p.C)[idx] = from_f32<T>(s);
 }
 
-template <typename T, int BM, int BN, bool MAIN>
+// packed factor: dst[j, k] = (T) src[j*sr + k*sk] for j < r, 0 for r <= j < 16
+template <typename T>
+__global__ __launch_bounds__(256) void pack_factor_kernel(const float* A, const float* B, T* A16, T* Bt16, int K,
+                                                          int N, int r) {
+    const int which = blockIdx.y;  // 0: A16[j,k] = A[j*K + k]   1: Bt16[j,n] = B[n*r + j]
+    const int len = which == 0 ? K : N;
+    T* dst = which == 0 ? A16 : Bt16;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < kRP * len; idx += gridDim.x * 256) {
+        const int j = idx / len, c = idx - j * len;
+        const int jj = j < r ? j : r - 1;
+        const float v = which == 0 ? A[(int64_t)jj * K + c] : B[(int64_t)c * r + jj];
+        dst[idx] = from_f32<T>(j < r ? v : 0.f);
+    }
+}
+
+// All layers of a slab in one launch.  table[l] = {a_off, b_off, K, N, r, a16_off, bt16_off, 0}: element
+// offsets of A[r,K] / B[N,r] inside `params` (fp32) and of the packed outputs inside `packed` (T).
+template <typename T>
+__global__ __launch_bounds__(256) void pack_factors_batched_kernel(const int64_t* table, const float* params,
+                                                                   T* packed) {
+    const int64_t* e = table + (int64_t)(blockIdx.y >> 1) * 8;
+    const int which = blockIdx.y & 1;
+    const int K = (int)e[2], N = (int)e[3], r = (int)e[4];
+    if (r > kRP) return;
+    const float* A = params + e[0];
+    const float* B = params + e[1];
+    const int len = which == 0 ? K : N;
+    T* dst = packed + (which == 0 ? e[5] : e[6]);
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < kRP * len; idx += gridDim.x * 256) {
+        const int j = idx / len, c = idx - j * len;
+        const int jj = j < r ? j : r - 1;
+        const float v = which == 0 ? A[(int64_t)jj * K + c] : B[(int64_t)c * r + jj];
+        dst[idx] = from_f32<T>(j < r ? v : 0.f);
+    }
+}
+
+template <typename T, int BM, int BN, bool MAIN, bool PIPE>
 int launch_tile(GemmParams p, hipStream_t stream) {
     p.tiles_m = (int)((p.M + BM - 1) / BM);
     p.tiles_n = MAIN ? (p.Nc + BN - 1) / BN : 1;
-    const int lds = gemm_lds_bytes<BM, BN, T>(MAIN);
-    auto kern = lora_gemm_kernel<T, BM, BN, MAIN>;
+    constexpr int lds = gemm_lds_bytes<BM, BN, T, MAIN, PIPE>();
+    auto kern = lora_gemm_kernel<T, BM, BN, MAIN, PIPE>;
     if (lds > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return LORA_E_LAUNCH;
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (attr != hipSuccess) return LORA_E_LAUNCH;
     }
     constexpr int prof_id = MAIN ? (BM == 128 && BN == 128 ? PK_GEMM_128x128 : (BM == 128 ? PK_GEMM_128x64 : PK_GEMM_64x64))
                                  : (BM == 128 ? PK_SKINNY_128 : PK_SKINNY_64);
@@ -445,66 +536,79 @@ int launch_tile(GemmParams p, hipStream_t stream) {
     return LORA_OK;
 }
 
-// Tile choice: fill 256 CUs × ~3 resident workgroups; prefer the tile with least padding waste.
-template <typename T, bool MAIN>
-int launch_fast(const GemmParams& p, hipStream_t stream) {
-    if (!MAIN) {
-        return p.M >= 128 * 192 ? launch_tile<T, 128, 64, false>(p, stream)
-                                : launch_tile<T, 64, 64, false>(p, stream);
-    }
-    struct Cand {
-        int bm, bn;
-    };
-    const Cand cands[3] = {{128, 128}, {128, 64}, {64, 64}};
-    double best = 1e30;
-    int pick = 2;
-    for (int i = 0; i < 3; ++i) {
-        const double tm = (double)((p.M + cands[i].bm - 1) / cands[i].bm);
-        const double tn = (double)((p.Nc + cands[i].bn - 1) / cands[i].bn);
-        const double tiles = tm * tn;
-        const double slots = 256.0 * (cands[i].bm * cands[i].bn >= 128 * 128 ? 2.0 : 4.0);
-        const double rounds = tiles <= slots ? 1.0 : tiles / slots;
-        // per-tile time model: MFMA work + operand traffic (smaller tiles re-read more)
-        const double work = (double)cands[i].bm * cands[i].bn + 24.0 * (cands[i].bm + cands[i].bn) + 3000.0;
-        const double cost = rounds * work;
-        if (cost < best) {
-            best = cost;
-            pick = i;
-        }
-    }
-    switch (pick) {
-        case 0: return launch_tile<T, 128, 128, true>(p, stream);
-        case 1: return launch_tile<T, 128, 64, true>(p, stream);
-        default: return launch_tile<T, 64, 64, true>(p, stream);
-    }
+int forced_tile() {  // tuning knob for tools/gemm_bench.py only
+    static const int forced = [] {
+        const char* e = getenv("LORA_FORCE_TILE");
+        return e ? atoi(e) : -1;
+    }();
+    return forced;
 }
 
+// Tile choice (measured on MI355X, tools/gemm_bench.py): the 128×128 tile wins once its grid fills at least
+// half the chip and the last column tile is not mostly padding; everything smaller or narrower runs 64×64
+// (two resident workgroups per CU, four times the workgroups).  128×64 never won and is not instantiated.
+template <typename T, bool MAIN>
+int launch_pipe(const GemmParams& p, hipStream_t stream) {
+    if (!MAIN) return launch_tile<T, 64, 64, false, true>(p, stream);
+    const int64_t tiles128 = ((p.M + 127) / 128) * ((p.Nc + 127) / 128);
+    const int padded = (p.Nc + 127) / 128 * 128;
+    bool big = tiles128 >= 128 && (padded - p.Nc) * 10 <= p.Nc;
+    if (forced_tile() == 0) big = true;
+    if (forced_tile() == 2) big = false;
+    return big ? launch_tile<T, 128, 128, true, true>(p, stream) : launch_tile<T, 64, 64, true, true>(p, stream);
+}
+
+struct CallArgs {  // what an entry point knows
+    const void* Am;
+    const void* Bm;
+    const void* bias;
+    const void* Fp;      // packed factor [16,Kc] (T)
+    const float* F;      // fp32 master of the same factor, strided (generic path)
+    int64_t f_sr, f_sk;
+    const float* Q;
+    int64_t q_sn, q_sj;
+    void* C;
+    float* P;
+    int64_t M;
+    int Kc, Nc, r;
+    float scale;
+};
+
 template <typename T>
-int launch_typed(const GemmParams& p, bool main_part, hipStream_t stream) {
+int launch_typed(const CallArgs& c, bool main_part, hipStream_t stream) {
     constexpr int VEC = ElemTraits<T>::kVec;
-    const bool fast = p.r <= kRP && (p.Kc % VEC) == 0 && aligned16(p.Am) &&
-                      (!main_part || ((p.Nc % VEC) == 0 && aligned16(p.Bm) && aligned16(p.C)));
-    if (fast) return main_part ? launch_fast<T, true>(p, stream) : launch_fast<T, false>(p, stream);
+    constexpr int BK = kRowBytes / (int)sizeof(T);
+    const bool fast = c.r <= kRP && c.Fp != nullptr && (c.Kc % VEC) == 0 && aligned16(c.Am) && aligned16(c.Fp) &&
+                      (!main_part || ((c.Nc % VEC) == 0 && aligned16(c.Bm) && aligned16(c.C)));
+    if (fast) {
+        GemmParams p{};
+        p.Am = c.Am; p.Bm = c.Bm; p.bias = c.bias; p.Fp = c.Fp; p.Q = c.Q; p.q_sn = c.q_sn; p.q_sj = c.q_sj;
+        p.C = c.C; p.P = c.P; p.M = c.M; p.Kc = c.Kc; p.Nc = c.Nc; p.r = c.r; p.scale = c.scale;
+        if ((c.Kc % BK) == 0) return main_part ? launch_pipe<T, true>(p, stream) : launch_pipe<T, false>(p, stream);
+        return main_part ? launch_tile<T, 64, 64, true, false>(p, stream) : launch_tile<T, 64, 64, false, false>(p, stream);
+    }
+    GenericParams g{};
+    g.Am = c.Am; g.Bm = c.Bm; g.bias = c.bias; g.F = c.F; g.f_sr = c.f_sr; g.f_sk = c.f_sk; g.Q = c.Q;
+    g.q_sn = c.q_sn; g.q_sj = c.q_sj; g.C = c.C; g.P = c.P; g.M = c.M; g.Kc = c.Kc; g.Nc = c.Nc; g.r = c.r;
+    g.scale = c.scale;
     {
-        const int64_t n = p.M * p.r;
-        hipLaunchKernelGGL(lora_skinny_generic_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                           stream, p);
+        const int64_t n = g.M * g.r;
+        hipLaunchKernelGGL(lora_skinny_generic_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g);
         LORA_LAUNCH_CHECK();
     }
     if (main_part) {
-        const int64_t n = p.M * p.Nc;
-        hipLaunchKernelGGL(lora_gemm_generic_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                           stream, p);
+        const int64_t n = g.M * g.Nc;
+        hipLaunchKernelGGL(lora_gemm_generic_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g);
         LORA_LAUNCH_CHECK();
     }
     return LORA_OK;
 }
 
-int launch_gemm(const GemmParams& p, bool main_part, int dtype, hipStream_t stream) {
+int launch_gemm(const CallArgs& c, bool main_part, int dtype, hipStream_t stream) {
     switch (dtype) {
-        case LORA_F32: return launch_typed<float>(p, main_part, stream);
-        case LORA_F16: return launch_typed<half_t>(p, main_part, stream);
-        case LORA_BF16: return launch_typed<bf16_t>(p, main_part, stream);
+        case LORA_F32: return launch_typed<float>(c, main_part, stream);
+        case LORA_F16: return launch_typed<half_t>(c, main_part, stream);
+        case LORA_BF16: return launch_typed<bf16_t>(c, main_part, stream);
         default: return LORA_E_BADARG;
     }
 }
@@ -520,45 +624,96 @@ double esize(int dtype) { return dtype == LORA_F32 ? 4.0 : 2.0; }
 
 }  // namespace
 
-extern "C" int lora_linear_fwd(const void* X, const void* W, const void* bias, const float* A,
-                               const float* B, void* Y, float* T_out, int64_t M, int K, int N, int r,
-                               float scale, int dtype, void* stream) {
+extern "C" int lora_pack_factors(const float* A, const float* B, void* A16, void* Bt16, int K, int N, int r,
+                                 int dtype, void* stream) {
+    if (!A || !B || !A16 || !Bt16 || K < 1 || N < 1) return LORA_E_BADARG;
+    if (r < 1 || r > (K < N ? K : N)) return LORA_E_RANK;
+    if (r > kRP) return LORA_OK;  // large ranks run on the generic kernels, which read the fp32 masters
+    const int len = K > N ? K : N;
+    dim3 grid((unsigned)((kRP * len + 255) / 256), 2);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case LORA_F32:
+            hipLaunchKernelGGL(pack_factor_kernel<float>, grid, dim3(256), 0, s, A, B, static_cast<float*>(A16),
+                               static_cast<float*>(Bt16), K, N, r);
+            break;
+        case LORA_F16:
+            hipLaunchKernelGGL(pack_factor_kernel<half_t>, grid, dim3(256), 0, s, A, B, static_cast<half_t*>(A16),
+                               static_cast<half_t*>(Bt16), K, N, r);
+            break;
+        case LORA_BF16:
+            hipLaunchKernelGGL(pack_factor_kernel<bf16_t>, grid, dim3(256), 0, s, A, B, static_cast<bf16_t*>(A16),
+                               static_cast<bf16_t*>(Bt16), K, N, r);
+            break;
+        default: return LORA_E_BADARG;
+    }
+    LORA_LAUNCH_CHECK();
+    return LORA_OK;
+}
+
+extern "C" int lora_pack_factors_batched(const int64_t* table, int n_layers, int max_len, const float* params,
+                                         void* packed, int dtype, void* stream) {
+    if (!table || !params || !packed || n_layers < 1 || max_len < 1) return LORA_E_BADARG;
+    dim3 grid((unsigned)((kRP * max_len + 255) / 256 > 64 ? 64 : (kRP * max_len + 255) / 256), 2 * n_layers);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case LORA_F32:
+            hipLaunchKernelGGL(pack_factors_batched_kernel<float>, grid, dim3(256), 0, s, table, params,
+                               static_cast<float*>(packed));
+            break;
+        case LORA_F16:
+            hipLaunchKernelGGL(pack_factors_batched_kernel<half_t>, grid, dim3(256), 0, s, table, params,
+                               static_cast<half_t*>(packed));
+            break;
+        case LORA_BF16:
+            hipLaunchKernelGGL(pack_factors_batched_kernel<bf16_t>, grid, dim3(256), 0, s, table, params,
+                               static_cast<bf16_t*>(packed));
+            break;
+        default: return LORA_E_BADARG;
+    }
+    LORA_LAUNCH_CHECK();
+    return LORA_OK;
+}
+
+extern "C" int lora_linear_fwd(const void* X, const void* W, const void* bias, const float* A, const float* B,
+                               const void* A16, void* Y, float* T_out, int64_t M, int K, int N, int r, float scale,
+                               int dtype, void* stream) {
     const int st = check_common(M, K, N, r, dtype);
     if (st != LORA_OK) return st;
     if (M == 0) return LORA_OK;  // empty batch: nothing to do (pointers may be null)
     if (!X || !W || !A || !B || !Y || !T_out) return LORA_E_BADARG;
-    GemmParams p{};
-    p.Am = X; p.Bm = W; p.bias = bias;
-    p.F = A; p.f_sr = K; p.f_sk = 1;   // F[j,k] = A[j,k]
-    p.Q = B; p.q_sn = r; p.q_sj = 1;   // Q[n,j] = B[n,j]
-    p.C = Y; p.P = T_out;
-    p.M = M; p.Kc = K; p.Nc = N; p.r = r; p.scale = scale;
+    CallArgs c{};
+    c.Am = X; c.Bm = W; c.bias = bias;
+    c.Fp = A16; c.F = A; c.f_sr = K; c.f_sk = 1;   // F[j,k] = A[j,k]
+    c.Q = B; c.q_sn = r; c.q_sj = 1;               // Q[n,j] = B[n,j]
+    c.C = Y; c.P = T_out;
+    c.M = M; c.Kc = K; c.Nc = N; c.r = r; c.scale = scale;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const double e = esize(dtype);
     ProfWork work(e * ((double)M * K + (double)N * K + (double)M * N) + e * r * (K + N) + (bias ? e * N : 0.0),
                   2.0 * M * K * N + 2.0 * M * r * (double)(K + N));
-    return launch_gemm(p, true, dtype, s);
+    return launch_gemm(c, true, dtype, s);
 }
 
 extern "C" int lora_linear_bwd_input(const void* dY, const void* Wt, const float* A, const float* B,
-                                     void* dX, float* U_out, int64_t M, int K, int N, int r, float scale,
-                                     int dtype, void* stream) {
+                                     const void* Bt16, void* dX, float* U_out, int64_t M, int K, int N, int r,
+                                     float scale, int dtype, void* stream) {
     const int st = check_common(M, K, N, r, dtype);
     if (st != LORA_OK) return st;
     if (M == 0) return LORA_OK;
     if (!dY || !A || !B || !U_out) return LORA_E_BADARG;
     if (dX && !Wt) return LORA_E_BADARG;
-    GemmParams p{};
-    p.Am = dY; p.Bm = Wt; p.bias = nullptr;
-    p.F = B; p.f_sr = 1; p.f_sk = r;   // F[j,n] = B[n,j]
-    p.Q = A; p.q_sn = 1; p.q_sj = K;   // Q[k,j] = A[j,k]
-    p.C = dX; p.P = U_out;
-    p.M = M; p.Kc = N; p.Nc = K; p.r = r; p.scale = scale;
+    CallArgs c{};
+    c.Am = dY; c.Bm = Wt; c.bias = nullptr;
+    c.Fp = Bt16; c.F = B; c.f_sr = 1; c.f_sk = r;  // F[j,n] = B[n,j]
+    c.Q = A; c.q_sn = 1; c.q_sj = K;               // Q[k,j] = A[j,k]
+    c.C = dX; c.P = U_out;
+    c.M = M; c.Kc = N; c.Nc = K; c.r = r; c.scale = scale;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const double e = esize(dtype);
     const double bytes = dX ? e * ((double)M * N + (double)N * K + (double)M * K) + e * r * (K + N)
                             : e * (double)M * N + e * r * N;
     const double flops = dX ? 2.0 * M * K * N + 2.0 * M * r * (double)(K + N) : 2.0 * M * r * (double)N;
     ProfWork work(bytes, flops);
-    return launch_gemm(p, dX != nullptr, dtype, s);
+    return launch_gemm(c, dX != nullptr, dtype, s);
 }

@@ -1,13 +1,18 @@
 // Gradients of the rank-r factors (base W frozen): the two tall-skinny reductions over M
-//     gB[N,r] += s·dYᵀ·T        gA[r,K] += s·Uᵀ·X          (T = X·Aᵀ, U = dY·B, both [M,r] fp32)
+//     gB[N,r] = s·dYᵀ·T        gA[r,K] = s·Uᵀ·X          (T = X·Aᵀ, U = dY·B, both [M,r] fp32)
 // — the autograd of lora_diffusion/lora.py:49-50 restricted to the parameters that
-// lora.py:179-180 mark trainable.  Both are  G[c,j] += s·Σ_m S[m,c]·P[m,j]  with a streamed
+// lora.py:179-180 mark trainable.  Both are  G[c,j] = s·Σ_m S[m,c]·P[m,j]  with a streamed
 // operand S ∈ {dY, X} read exactly once, so this is an HBM-streaming kernel:
-//   - a thread owns one 16-byte column chunk (8 halfs / 4 floats) and walks rows; r×VEC fp32
-//     accumulators stay in VGPRs; the P row (r floats) is a broadcast load;
-//   - 256 threads cover ⌊256/CL⌋ rows per pass when the strip is narrower than the workgroup;
-//   - partial sums of the row groups are combined with LDS float atomics, then written with
-//     CONTIGUOUS global float atomics (256-B runs) into the flat gradient slab.
+//   - a thread owns one 16-byte column chunk (8 halfs / 4 floats) and walks rows, UNROLL rows per trip so
+//     several independent loads are in flight; r×VEC fp32 accumulators stay in VGPRs; the P row is a
+//     broadcast load;
+//   - 256 threads cover ⌊256/CL⌋ rows per pass when the strip is narrower than the workgroup; the row
+//     groups are combined with LDS float adds;
+//   - the M range is cut into `n_blocks` row blocks; each block STORES its partial sums (plain 16-B-friendly
+//     stores, no global atomics: the outputs are only a few KB wide, and atomics from hundreds of
+//     workgroups onto so few cache lines serialise at the memory side);
+//   - lora_reduce_partials sums the row blocks in index order (deterministic) — one launch for the whole
+//     gradient slab of a model, or one per call in the plain autograd mode.
 // Both problems of a layer go out in ONE launch (blockIdx.z selects dY→gB or X→gA).
 #include "common.h"
 
@@ -16,7 +21,7 @@ namespace {
 struct GradProblem {
     const void* S;    // [M, C]
     const float* P;   // [M, r]
-    float* G;         // output
+    float* G;         // partial output of row block 0
     int C;
     int out_kn;       // 1: G is [r, C] (gA layout: j*C + c); 0: G is [C, r] (gB layout: c*r + j)
     int CL;           // column chunks (threads) per row inside a strip
@@ -25,10 +30,13 @@ struct GradProblem {
 struct GradParams {
     GradProblem prob[2];
     int64_t M;
+    int64_t part_stride;  // floats between consecutive row blocks' partials
     int r;
     int rows_per_block;
     float scale;
 };
+
+constexpr int kUnroll = 8;
 
 template <typename T, int RP /* padded rank: 4, 8, 16 */>
 __global__ __launch_bounds__(256) void lora_grad_kernel(GradParams p) {
@@ -57,24 +65,36 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(GradParams p) {
     int64_t m_end = m_begin + p.rows_per_block;
     if (m_end > p.M) m_end = p.M;
 
-    if (active) {
+    if (active && m_begin < m_end) {
         const T* S = static_cast<const T*>(q.S) + c0 + c_local;
-        for (int64_t m = m_begin + rsub; m < m_end; m += rows_pp) {
-            const Chunk<T> s = *reinterpret_cast<const Chunk<T>*>(S + m * q.C);
-            float pv[RP];
+        const int64_t last = m_end - 1;
+        for (int64_t m = m_begin + rsub; m < m_end; m += (int64_t)rows_pp * kUnroll) {
+            // kUnroll independent rows per trip; loads are unconditional from clamped rows (a load under
+            // a per-lane condition is branched around and waited for one by one), tails are zero-weighted
+            Chunk<T> s[kUnroll];
+            float pv[kUnroll][RP];
 #pragma unroll
-            for (int j = 0; j < RP; ++j) pv[j] = j < p.r ? q.P[m * p.r + j] : 0.f;
-            float sv[VEC];
+            for (int u = 0; u < kUnroll; ++u) {
+                const int64_t mu = m + (int64_t)u * rows_pp;
+                const int64_t ml = mu < m_end ? mu : last;
+                s[u] = *reinterpret_cast<const Chunk<T>*>(S + ml * q.C);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) sv[e] = to_f32<T>(s.v[e]);
+                for (int j = 0; j < RP; ++j) pv[u][j] = q.P[ml * p.r + (j < p.r ? j : p.r - 1)];
+            }
 #pragma unroll
-            for (int j = 0; j < RP; ++j)
+            for (int u = 0; u < kUnroll; ++u) {
+                const bool ok = m + (int64_t)u * rows_pp < m_end;
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[j][e] = fmaf(sv[e], pv[j], acc[j][e]);
+                for (int j = 0; j < RP; ++j) {
+                    const float w = (ok && j < p.r) ? pv[u][j] : 0.f;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[j][e] = fmaf(to_f32<T>(s[u].v[e]), w, acc[j][e]);
+                }
+            }
         }
     }
 
-    // combine row groups: LDS image [j][c_local] (j-major), zero → ds_add → contiguous flush
+    // combine the row groups: LDS image [j][c_local] (j-major), zero → ds_add → plain store
     const int total = p.r * stripW;
     for (int i = tid; i < total; i += 256) sred[i] = 0.f;
     __syncthreads();
@@ -88,22 +108,23 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(GradParams p) {
         }
     }
     __syncthreads();
+    float* G = q.G + (int64_t)blockIdx.y * p.part_stride;
     if (q.out_kn) {
         // gA[j, c0 + c]: every j row is a contiguous run of stripW floats
         for (int i = tid; i < total; i += 256) {
             const int j = i / stripW, c = i - j * stripW;
-            atomicAdd(q.G + (int64_t)j * q.C + c0 + c, p.scale * sred[i]);
+            G[(int64_t)j * q.C + c0 + c] = p.scale * sred[i];
         }
     } else {
         // gB[(c0 + c), j]: the whole strip block is one contiguous run of stripW·r floats
         for (int i = tid; i < total; i += 256) {
             const int c = i / p.r, j = i - c * p.r;
-            atomicAdd(q.G + (int64_t)c0 * p.r + i, p.scale * sred[j * stripW + c]);
+            G[(int64_t)c0 * p.r + i] = p.scale * sred[j * stripW + c];
         }
     }
 }
 
-// Unaligned / large-rank path: one thread per output element, serial over M.  Correct, not fast.
+// Unaligned / large-rank path: one thread per output element, serial over the row block.  Correct, not fast.
 template <typename T>
 __global__ void lora_grad_generic_kernel(GradParams p) {
     const GradProblem& q = p.prob[blockIdx.z];
@@ -111,21 +132,47 @@ __global__ void lora_grad_generic_kernel(GradParams p) {
     if (idx >= (int64_t)q.C * p.r) return;
     const int c = (int)(idx / p.r), j = (int)(idx % p.r);
     const T* S = static_cast<const T*>(q.S);
+    const int64_t m_begin = (int64_t)blockIdx.y * p.rows_per_block;
+    int64_t m_end = m_begin + p.rows_per_block;
+    if (m_end > p.M) m_end = p.M;
     float s = 0.f;
-    for (int64_t m = 0; m < p.M; ++m) s = fmaf(to_f32<T>(S[m * q.C + c]), q.P[m * p.r + j], s);
-    float* dst = q.out_kn ? q.G + (int64_t)j * q.C + c : q.G + idx;
-    atomicAdd(dst, p.scale * s);
+    for (int64_t m = m_begin; m < m_end; ++m) s = fmaf(to_f32<T>(S[m * q.C + c]), q.P[m * p.r + j], s);
+    float* G = q.G + (int64_t)blockIdx.y * p.part_stride;
+    (q.out_kn ? G[(int64_t)j * q.C + c] : G[idx]) = p.scale * s;
+}
+
+// grads[i] (+)= Σ_b partials[b·stride + i], b ascending: deterministic.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* partials, int64_t stride, int n_blocks,
+                                                              float* grads, int64_t n, int accumulate) {
+    const int64_t nvec = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        float4 s = accumulate ? reinterpret_cast<const float4*>(grads)[i] : float4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < n_blocks; ++b) {
+            const float4 v = *reinterpret_cast<const float4*>(partials + (int64_t)b * stride + 4 * i);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        reinterpret_cast<float4*>(grads)[i] = s;
+    }
+    if (blockIdx.x == 0) {
+        for (int64_t i = (nvec << 2) + threadIdx.x; i < n; i += 256) {
+            float s = accumulate ? grads[i] : 0.f;
+            for (int b = 0; b < n_blocks; ++b) s += partials[(int64_t)b * stride + i];
+            grads[i] = s;
+        }
+    }
 }
 
 template <typename T>
-int launch_grad(GradParams p, hipStream_t stream) {
+int launch_grad(GradParams p, int n_blocks, hipStream_t stream) {
     constexpr int VEC = ElemTraits<T>::kVec;
+    p.rows_per_block = (int)((p.M + n_blocks - 1) / n_blocks);
+    if (p.rows_per_block < 1) p.rows_per_block = 1;
     bool fast = p.r <= 16;
     for (int i = 0; i < 2; ++i) fast = fast && (p.prob[i].C % VEC) == 0 && aligned16(p.prob[i].S);
     if (!fast) {
         int cmax = p.prob[0].C > p.prob[1].C ? p.prob[0].C : p.prob[1].C;
         const int64_t n = (int64_t)cmax * p.r;
-        hipLaunchKernelGGL(lora_grad_generic_kernel<T>, dim3((unsigned)((n + 255) / 256), 1, 2), dim3(256), 0,
+        hipLaunchKernelGGL(lora_grad_generic_kernel<T>, dim3((unsigned)((n + 255) / 256), n_blocks, 2), dim3(256), 0,
                            stream, p);
         LORA_LAUNCH_CHECK();
         return LORA_OK;
@@ -145,13 +192,7 @@ int launch_grad(GradParams p, hipStream_t stream) {
         const int lds = p.r * q.CL * VEC * 4;
         if (lds > max_lds) max_lds = lds;
     }
-    // rows per block: aim at ~1024 workgroups over both problems, at least 32 rows each
-    const int64_t want_blocks = 1024 / (2 * max_strips) > 0 ? 1024 / (2 * max_strips) : 1;
-    int64_t rpb = (p.M + want_blocks - 1) / want_blocks;
-    if (rpb < 32) rpb = 32;
-    p.rows_per_block = (int)rpb;
-    const unsigned gy = (unsigned)((p.M + rpb - 1) / rpb);
-    dim3 grid(max_strips, gy, 2);
+    dim3 grid(max_strips, n_blocks, 2);
     switch (rp) {
         case 4: LORA_LAUNCH(PK_GRAD_R4, (lora_grad_kernel<T, 4>), grid, dim3(256), max_lds, stream, p); break;
         case 8: LORA_LAUNCH(PK_GRAD_R8, (lora_grad_kernel<T, 8>), grid, dim3(256), max_lds, stream, p); break;
@@ -164,26 +205,37 @@ int launch_grad(GradParams p, hipStream_t stream) {
 }  // namespace
 
 extern "C" int lora_linear_bwd_params(const void* dY, const void* X, const float* T, const float* U,
-                                      float* gA, float* gB, int64_t M, int K, int N, int r, float scale,
-                                      int dtype, void* stream) {
-    if (M < 0 || K <= 0 || N <= 0) return LORA_E_BADARG;
+                                      float* gA_part, float* gB_part, int64_t part_stride, int n_blocks,
+                                      int64_t M, int K, int N, int r, float scale, int dtype, void* stream) {
+    if (M < 0 || K <= 0 || N <= 0 || n_blocks < 1) return LORA_E_BADARG;
     if (r < 1 || r > (K < N ? K : N)) return LORA_E_RANK;
-    if (M == 0) return LORA_OK;
-    if (!dY || !X || !T || !U || !gA || !gB) return LORA_E_BADARG;
+    if (!gA_part || !gB_part) return LORA_E_BADARG;
+    if (M > 0 && (!dY || !X || !T || !U)) return LORA_E_BADARG;
     GradParams p{};
-    p.prob[0].S = dY; p.prob[0].P = T; p.prob[0].G = gB; p.prob[0].C = N; p.prob[0].out_kn = 0;
-    p.prob[1].S = X;  p.prob[1].P = U; p.prob[1].G = gA; p.prob[1].C = K; p.prob[1].out_kn = 1;
-    p.M = M; p.r = r; p.scale = scale;
+    p.prob[0].S = dY; p.prob[0].P = T; p.prob[0].G = gB_part; p.prob[0].C = N; p.prob[0].out_kn = 0;
+    p.prob[1].S = X;  p.prob[1].P = U; p.prob[1].G = gA_part; p.prob[1].C = K; p.prob[1].out_kn = 1;
+    p.M = M; p.r = r; p.scale = scale; p.part_stride = part_stride;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const double e = dtype == LORA_F32 ? 4.0 : 2.0;
     ProfWork work(e * ((double)M * N + (double)M * K) + 4.0 * r * (double)(K + N) + 8.0 * M * r,
                   2.0 * M * r * (double)(K + N));
-    int rc;
     switch (dtype) {
-        case LORA_F32: rc = launch_grad<float>(p, s); break;
-        case LORA_F16: rc = launch_grad<half_t>(p, s); break;
-        case LORA_BF16: rc = launch_grad<bf16_t>(p, s); break;
-        default: rc = LORA_E_BADARG;
+        case LORA_F32: return launch_grad<float>(p, n_blocks, s);
+        case LORA_F16: return launch_grad<half_t>(p, n_blocks, s);
+        case LORA_BF16: return launch_grad<bf16_t>(p, n_blocks, s);
+        default: return LORA_E_BADARG;
     }
-    return rc;
+}
+
+extern "C" int lora_reduce_partials(const float* partials, int64_t part_stride, int n_blocks, float* grads,
+                                    int64_t n, int accumulate, void* stream) {
+    if (!partials || !grads || n < 1 || n_blocks < 1) return LORA_E_BADARG;
+    if (!aligned16(partials) || !aligned16(grads) || (part_stride & 3)) return LORA_E_ALIGN;
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       partials, part_stride, n_blocks, grads, n, accumulate);
+    LORA_LAUNCH_CHECK();
+    return LORA_OK;
 }

@@ -68,7 +68,7 @@ class _LoraLinearFn(torch.autograd.Function):
     """y = x·Wᵀ + b + s·(x·Aᵀ)·Bᵀ with grads for x, A (down) and B (up) only."""
 
     @staticmethod
-    def forward(ctx, x, down, up, w, wt, bias, scale, grad_sink):
+    def forward(ctx, x, down, up, w, wt, bias, scale, grad_sink, packed):
         K = w.shape[1]
         N = w.shape[0]
         x2 = x.reshape(-1, K)
@@ -78,8 +78,12 @@ class _LoraLinearFn(torch.autograd.Function):
             x2 = x2.contiguous()
         a = _as_f32(down)
         b = _as_f32(up)
-        y2, t = nat.lora_linear_fwd(x2, w, bias, a, b, scale)
+        # packed factors: the trainer keeps them current for the whole slab (one launch per optimizer step);
+        # otherwise they are cast here, once per call, like autocast casts lora_down/lora_up in the reference
+        a16, bt16 = packed if packed is not None else nat.lora_pack_factors(a, b, w.dtype)
+        y2, t = nat.lora_linear_fwd(x2, w, bias, a, b, scale, a16)
         ctx.save_for_backward(x2, a, b, t)
+        ctx.bt16 = bt16
         ctx.wt = wt
         ctx.scale = float(scale)
         ctx.x_shape = x.shape
@@ -102,13 +106,16 @@ class _LoraLinearFn(torch.autograd.Function):
             dy2 = dy2.contiguous()
         if need_dx and ctx.wt is None:
             raise RuntimeError("lora_linear backward: Wᵀ operand was not prepared in forward")
-        dx2, u = nat.lora_linear_bwd_input(dy2, ctx.wt if need_dx else None, a, b, ctx.scale, need_dx)
+        dx2, u = nat.lora_linear_bwd_input(dy2, ctx.wt if need_dx else None, a, b, ctx.scale, need_dx, ctx.bt16)
         g_down = g_up = None
         if need_factors:
             sink = ctx.grad_sink
             if sink is not None:
-                # trainer mode: accumulate straight into the flat gradient slab (also the RCCL buffer)
-                nat.lora_linear_bwd_params(dy2, x2, t, u, sink[0], sink[1], ctx.scale)
+                # trainer mode: row-block partials go straight into the model-wide partial slab; the trainer
+                # reduces the whole slab (= the RCCL buffer) in one launch after backward
+                ga_part, gb_part, stride, n_blocks, ran = sink
+                nat.lora_linear_bwd_params_partial(dy2, x2, t, u, ga_part, gb_part, stride, n_blocks, ctx.scale)
+                ran[0] += 1
             else:
                 g_down = torch.zeros_like(a)
                 g_up = torch.zeros_like(b)
@@ -122,7 +129,7 @@ class _LoraLinearFn(torch.autograd.Function):
             dx = dx2.view(ctx.x_shape)
             if dx.dtype != ctx.x_dtype:
                 dx = dx.to(ctx.x_dtype)
-        return dx, g_down, g_up, None, None, None, None, None
+        return dx, g_down, g_up, None, None, None, None, None, None
 
 
 def lora_linear(module, x: torch.Tensor) -> torch.Tensor:
@@ -145,7 +152,10 @@ def lora_linear(module, x: torch.Tensor) -> torch.Tensor:
     need_wt = torch.is_grad_enabled() and x.requires_grad
     w, wt, bias = _frozen_operands(module, cdtype, need_wt)
     sink = module.__dict__.get("_dfa_grad_sink")
-    return _LoraLinearFn.apply(x, down, up, w, wt, bias, float(module.scale), sink)
+    packed = module.__dict__.get("_dfa_packed")
+    if packed is not None and packed[0].dtype != cdtype:
+        packed = None
+    return _LoraLinearFn.apply(x, down, up, w, wt, bias, float(module.scale), sink, packed)
 
 
 class _DDPMLossFn(torch.autograd.Function):

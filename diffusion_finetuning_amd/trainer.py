@@ -46,7 +46,10 @@ class LoraSlab:
     storage moves.  Each layer gets `_dfa_grad_sink = (grad_down_view, grad_up_view)` so the backward kernel
     accumulates in place, and `.grad` of each Parameter is a view of the gradient slab."""
 
+    GRAD_BLOCKS = 128
+
     def __init__(self, models: Sequence[nn.Module]):
+        self._ran = []
         self.layers: List[LoraInjectedLinear] = []
         self.model_ranges: List[Tuple[int, int]] = []
         for model in models:
@@ -62,8 +65,12 @@ class LoraSlab:
         total = sum(l.lora_up.weight.numel() + l.lora_down.weight.numel() for l in self.layers)
         pad = (-total) % 4  # keep 16-byte granularity for vector loads
         self.numel = total
+        self.stride = total + pad
         self.params = torch.zeros(total + pad, dtype=torch.float32, device=device)
         self.grads = torch.zeros(total + pad, dtype=torch.float32, device=device)
+        # row-block partial sums of the factor gradients, [GRAD_BLOCKS][slab]: written by the backward kernels
+        # with plain stores, summed in block order by ONE launch per step (deterministic, no atomics)
+        self.partials = torch.zeros((self.GRAD_BLOCKS, total + pad), dtype=torch.float32, device=device)
         self.offsets = []
         off = 0
         for layer in self.layers:
@@ -79,14 +86,72 @@ class LoraSlab:
                 views[attr] = gv
                 self.offsets.append((off, n))
                 off += n
-            layer.__dict__["_dfa_grad_sink"] = (views["lora_down"], views["lora_up"])
+            starts = {a: self.offsets[-2 + i][0] for i, a in enumerate(("lora_up", "lora_down"))}
+            ran = [0]
+            self._ran.append(ran)
+            layer.__dict__["_dfa_grad_sink"] = (self.partials[0, starts["lora_down"]:], self.partials[0, starts["lora_up"]:],
+                                                self.stride, self.GRAD_BLOCKS, ran)
+
+    def enable_packed(self, dtype: torch.dtype):
+        """Allocates the packed-factor slab ([16,K] + [16,N] per layer in the compute dtype) and the device
+        table for the one-launch re-pack; each layer gets `_dfa_packed = (A16, Bt16)` views."""
+        rows = []
+        off = 0
+        self._packed_layers = []
+        for i, layer in enumerate(self.layers):
+            r, K = layer.lora_down.weight.shape
+            N = layer.lora_up.weight.shape[0]
+            if r > 16:
+                continue
+            up_off, down_off = self.offsets[2 * i][0], self.offsets[2 * i + 1][0]
+            rows.append([down_off, up_off, K, N, r, off, off + 16 * K, 0])
+            self._packed_layers.append((layer, off, K, N))
+            off += 16 * (K + N)
+        if not rows:
+            self.packed = None
+            return
+        self.packed = torch.zeros(off, dtype=dtype, device=self.params.device)
+        self._pack_table = torch.tensor(rows, dtype=torch.int64, device=self.params.device)
+        self._pack_maxlen = max(max(r_[2], r_[3]) for r_ in rows)
+        for layer, o, K, N in self._packed_layers:
+            layer.__dict__["_dfa_packed"] = (self.packed[o:o + 16 * K].view(16, K),
+                                             self.packed[o + 16 * K:o + 16 * (K + N)].view(16, N))
+        self.repack()
+
+    def repack(self):
+        """Refresh every packed factor from the fp32 master slab (one launch)."""
+        if getattr(self, "packed", None) is not None:
+            nat.lora_pack_factors_batched(self._pack_table, len(self._packed_layers), self._pack_maxlen, self.params,
+                                          self.packed)
 
     def zero_grad(self):
         self.grads.zero_()
+        for ran in self._ran:
+            ran[0] = 0
+
+    def check_all_layers_ran(self):
+        """A layer that did not run backward in this pass still holds an older pass's partials: clear those
+        slices before they are reduced (never the case for a UNet step)."""
+        for i, ran in enumerate(self._ran):
+            if ran[0] == 0:
+                a = self.offsets[2 * i][0]
+                b = self.offsets[2 * i + 1][0] + self.offsets[2 * i + 1][1]
+                self.partials[:, a:b].zero_()
+            elif ran[0] > 1:
+                raise RuntimeError("a LoRA layer ran backward more than once in one pass (shared module?): "
+                                   "the partial-sum layout holds one pass per layer")
+            ran[0] = 0
+
+    def reduce_range(self, a: int, b: int):
+        """grads[a:b] += Σ_blocks partials[:, a:b] (block order, deterministic)."""
+        if a % 4:
+            raise RuntimeError("slab range must start on a 16-byte boundary")
+        nat.lora_reduce_partials(self.partials[0, a:], self.stride, self.GRAD_BLOCKS, self.grads[a:], b - a, True)
 
     def detach_sinks(self):
         for layer in self.layers:
             layer.__dict__.pop("_dfa_grad_sink", None)
+            layer.__dict__.pop("_dfa_packed", None)
 
     def range_of(self, module: nn.Module) -> Tuple[int, int]:
         """[start, end) of the slab covering the LoRA layers under `module` (must be contiguous)."""
@@ -137,43 +202,53 @@ class SlabExchange:
     """Synchronous data-parallel exchange of the flat gradient slab: SUM all-reduce in at most two buckets
     (the mean's 1/world is folded into the optimizer's grad_mul).  The reference gets the same effect
     implicitly from DDP inside accelerator.backward (train_lora_dreambooth.py:744-757,877).  Device-agnostic:
-    RCCL ("nccl") on the GPUs, gloo in the CPU tests."""
+    RCCL ("nccl") on the GPUs, gloo in the CPU tests.
 
-    def __init__(self, grads: torch.Tensor, numel: int, process_group=None):
-        self.grads, self.numel, self.pg = grads, numel, process_group
+    `prepare(a, b)` (optional) is called for every slab range right before it is sent — the trainer uses it to
+    fold the row-block partial sums of that range into the gradient slab — and also when world == 1."""
+
+    def __init__(self, grads: torch.Tensor, numel: int, process_group=None, prepare=None):
+        self.grads, self.numel, self.pg, self.prepare = grads, numel, process_group, prepare
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.early_range: Optional[Tuple[int, int]] = None
         self._armed = False
+        self._early_sent = False
         self._pending = []
 
     def arm(self):
         """Call before each backward pass; launch_early() then fires at most once."""
         self._armed = self.world > 1 and self.early_range is not None
+        self._early_sent = False
+
+    def _send(self, a: int, b: int):
+        if b <= a:
+            return
+        if self.prepare is not None:
+            self.prepare(a, b)
+        if self.world > 1:
+            self._pending.append(dist.all_reduce(self.grads[a:b], group=self.pg, async_op=True))
 
     def launch_early(self):
         """Start reducing the early bucket (its gradients are final) while backward continues."""
         if self._armed:
             self._armed = False
-            a, b = self.early_range
-            self._pending.append(dist.all_reduce(self.grads[a:b], group=self.pg, async_op=True))
+            self._early_sent = True
+            self._send(*self.early_range)
 
     def finish(self):
-        """Reduce whatever has not been sent yet and wait for every bucket."""
-        if self.world == 1:
-            return
+        """Send whatever has not been sent yet and wait for every bucket."""
         n = self.numel
-        if self._pending:
+        if self._early_sent:
             a, b = self.early_range
-            if a > 0:
-                self._pending.append(dist.all_reduce(self.grads[:a], group=self.pg, async_op=True))
-            if b < n:
-                self._pending.append(dist.all_reduce(self.grads[b:n], group=self.pg, async_op=True))
+            self._send(0, a)
+            self._send(b, n)
         else:
-            self._pending.append(dist.all_reduce(self.grads[:n], group=self.pg, async_op=True))
+            self._send(0, n)
         for w in self._pending:
             w.wait()
         self._pending = []
         self._armed = False
+        self._early_sent = False
 
 
 class LoraTrainer:
@@ -193,11 +268,12 @@ class LoraTrainer:
         self.device = self.slab.params.device
         self.dtype = next(p for p in unet.parameters() if p.dim() == 4).dtype  # conv weight dtype = compute dtype
         self.loss_scale = float(loss_scale) if loss_scale is not None else (1024.0 if self.dtype == torch.float16 else 1.0)
+        self.slab.enable_packed(self.dtype)
         self.v_prediction = v_prediction
         self.sqrt_acp, self.sqrt_1macp = ddpm_tables(device=self.device)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
-        self.exchange = SlabExchange(self.slab.grads, self.slab.numel, process_group)
+        self.exchange = SlabExchange(self.slab.grads, self.slab.numel, process_group, prepare=self.slab.reduce_range)
         if self.world > 1:
             self._broadcast_initial_state()
             self._install_bucket_hook()
@@ -228,6 +304,7 @@ class LoraTrainer:
              prior_loss_weight=1.0, mask=None):
         """latents/noise fp32 [B,4,h,w] on the device, timesteps int64 [B], encoder_hidden_states [B,L,D]."""
         self.slab.zero_grad()
+        self.slab.repack()  # packed compute-dtype factors follow the fp32 masters (also after external edits)
         noisy, target = nat.ddpm_add_noise(latents, noise, timesteps, self.sqrt_acp, self.sqrt_1macp, self.dtype,
                                            self.v_prediction)
         self.exchange.arm()
@@ -241,6 +318,7 @@ class LoraTrainer:
         pred_c = pred if pred.is_contiguous() else pred.contiguous()
         loss, dpred = nat.ddpm_mse_fwd_bwd(pred_c, target, m, n_inst, n_prior, prior_loss_weight, self.loss_scale)
         pred_c.backward(dpred)
+        self.slab.check_all_layers_ran()
         self.exchange.finish()
         self.opt.step(grad_mul=1.0 / (self.world * self.loss_scale))
         return loss

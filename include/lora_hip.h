@@ -49,14 +49,32 @@ int lora_version(void);
 const char* lora_status_string(int status);
 
 /*
+ * Packed rank-r factors.  The fused kernels stream the factor that is contracted in their main loop as a
+ * 16-row operand tile in the compute dtype (rows >= r are zero):
+ *     A16 [16,K]  : A16[j,k]  = (dtype) A[j,k]      — forward  (T = X·Aᵀ)
+ *     Bt16[16,N]  : Bt16[j,n] = (dtype) B[n,j]      — backward (U = dY·B)
+ * i.e. the same cast of lora_down / lora_up to the compute dtype the reference gets from autocast on
+ * lora.py:50.  Re-pack whenever A or B changed (once per optimizer step).  The batched form packs every
+ * layer of a flat parameter slab in ONE launch: table[l] = {a_off, b_off, K, N, r, a16_off, bt16_off, 0}
+ * (int64, device memory; element offsets into `params` resp. `packed`), max_len = max over layers of max(K,N).
+ * For r > 16 nothing is packed (those ranks run on the shape-agnostic kernels that read the fp32 masters).
+ */
+int lora_pack_factors(const float* A, const float* B, void* A16, void* Bt16, int K, int N, int r,
+                      int dtype, void* stream);
+int lora_pack_factors_batched(const int64_t* table, int n_layers, int max_len, const float* params,
+                              void* packed, int dtype, void* stream);
+
+/*
  * Forward of LoraInjectedLinear.forward — lora_diffusion/lora.py:49-50
  *     Y = X·Wᵀ + b + s·((X·Aᵀ)·Bᵀ)
  * replaces F.linear ×3 + mul + add (5 launches + the [M,N] LoRA temporary) with one kernel.
- * T_out (nullable) receives T = X·Aᵀ [M,r] fp32 for the backward.
+ * A, B: fp32 masters; A16: packed A (nullable → shape-agnostic slow path).
+ * T_out receives T = X·Aᵀ [M,r] fp32 for the backward.
  */
 int lora_linear_fwd(const void* X, const void* W, const void* bias /* nullable */,
-                    const float* A, const float* B, void* Y, float* T_out /* nullable */,
-                    int64_t M, int K, int N, int r, float scale, int dtype, void* stream);
+                    const float* A, const float* B, const void* A16 /* nullable */, void* Y,
+                    float* T_out, int64_t M, int K, int N, int r, float scale, int dtype,
+                    void* stream);
 
 /*
  * Backward w.r.t. the input — autograd of lora.py:49-50 as driven by
@@ -65,23 +83,31 @@ int lora_linear_fwd(const void* X, const void* W, const void* bias /* nullable *
  *     dX = dY·W + s·U·A                 [M,K]  (skipped when dX == NULL: attn2 to_k/to_v with a
  *                                               frozen text encoder need no input gradient)
  * Wt is the frozen weight stored TRANSPOSED, Wt[K,N] = Wᵀ, so that the contraction index n is
- * contiguous for both operands (the caller caches Wt once per frozen layer).
+ * contiguous for both operands (the caller caches Wt once per frozen layer).  Bt16: packed Bᵀ
+ * (nullable → shape-agnostic slow path).
  */
 int lora_linear_bwd_input(const void* dY, const void* Wt, const float* A, const float* B,
-                          void* dX /* nullable */, float* U_out, int64_t M, int K, int N, int r,
-                          float scale, int dtype, void* stream);
+                          const void* Bt16 /* nullable */, void* dX /* nullable */, float* U_out,
+                          int64_t M, int K, int N, int r, float scale, int dtype, void* stream);
 
 /*
  * Backward w.r.t. the LoRA factors (no grad for W or b: lora.py:179-180 set requires_grad only on
  * lora_up / lora_down; train_lora_dreambooth.py:595 freezes the rest):
- *     gB += s·dYᵀ·T      [N,r]
- *     gA += s·Uᵀ·X       [r,K]
- * ACCUMULATES (fp32 atomic add) into gA / gB, which the caller zeroes once per optimizer step —
- * they are normally slices of one flat gradient slab that is also the RCCL all-reduce buffer.
+ *     gB = s·dYᵀ·T      [N,r]
+ *     gA = s·Uᵀ·X       [r,K]
+ * The M rows are cut into `n_blocks` row blocks; block b STORES its partial sums at
+ * gA_part + b·part_stride and gB_part + b·part_stride (fp32; every block is written, zeros included).
+ * No global atomics: the outputs are a few KB wide and hundreds of workgroups adding onto so few cache
+ * lines serialise at the memory side.  lora_reduce_partials then sums the blocks in index order
+ * (deterministic): grads[i] (+)= Σ_b partials[b·part_stride + i] for i < n.  A trainer lays the partials
+ * of all layers out as [n_blocks][slab] and reduces the whole slab — the RCCL all-reduce buffer — in
+ * one launch per step.
  */
 int lora_linear_bwd_params(const void* dY, const void* X, const float* T, const float* U,
-                           float* gA, float* gB, int64_t M, int K, int N, int r, float scale,
-                           int dtype, void* stream);
+                           float* gA_part, float* gB_part, int64_t part_stride, int n_blocks,
+                           int64_t M, int K, int N, int r, float scale, int dtype, void* stream);
+int lora_reduce_partials(const float* partials, int64_t part_stride, int n_blocks, float* grads,
+                         int64_t n, int accumulate, void* stream);
 
 /*
  * DDPM noise-prediction loss, forward + gradient in one pass —
