@@ -176,7 +176,10 @@ def lora_linear_bwd_input(dy2, wt, a, b, scale: float, need_dx: bool, bt16=None)
 
 def grad_blocks_for(M: int) -> int:
     """Row blocks for the factor-gradient kernel when the caller has no fixed layout (plain autograd mode)."""
-    return max(1, min(128, (M + 15) // 16))
+    forced = os.environ.get("LORA_GRAD_BLOCKS")  # tuning knob for tools/gemm_bench.py
+    if forced:
+        return int(forced)
+    return max(1, min(128, M // 32))
 
 
 def lora_linear_bwd_params_partial(dy2, x2, t, u, ga_part, gb_part, part_stride: int, n_blocks: int, scale: float):

@@ -48,7 +48,6 @@ struct GemmParams {
 
 constexpr int kRowBytes = 128;  // one K-step of one tile row
 constexpr int kRP = 16;         // rank padded to one MFMA fragment
-constexpr int kStages = 3;      // LDS ring depth of the PIPE loop
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * kRowBytes + ((chunk ^ (row & 7)) << 4);
@@ -78,8 +77,8 @@ template <> struct Mfma<bf16_t> {
 template <int BM, int BN, bool MAIN> constexpr int stage_bytes() {
     return (BM + (MAIN ? BN : 0) + 2 * kRP) * kRowBytes;
 }
-template <int BM, int BN, typename T, bool MAIN, bool PIPE> constexpr int gemm_lds_bytes() {
-    constexpr int ring = (PIPE ? kStages : 1) * stage_bytes<BM, BN, MAIN>();
+template <int BM, int BN, typename T, bool MAIN, int STG> constexpr int gemm_lds_bytes() {
+    constexpr int ring = (STG > 0 ? STG : 1) * stage_bytes<BM, BN, MAIN>();
     constexpr int sq = MAIN ? BN * kRP * (int)sizeof(T) : 0;
     constexpr int ep = sizeof(T) == 4 ? 2 : 1;
     constexpr int sc = MAIN ? (BM / ep) * (BN * (int)sizeof(T) + 16) : 0;
@@ -89,8 +88,11 @@ template <int BM, int BN, typename T, bool MAIN, bool PIPE> constexpr int gemm_l
     return a > b ? a : b;
 }
 
-template <typename T, int BM, int BN, bool MAIN, bool PIPE>
+// STG: LDS ring depth of the DMA pipeline (2 or 3); 0 selects the register-staged fallback loop.
+template <typename T, int BM, int BN, bool MAIN, int STG>
 __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
+    constexpr bool PIPE = STG > 0;
+    constexpr int kStages = PIPE ? STG : 1;
     constexpr int VEC = ElemTraits<T>::kVec;
     constexpr int BK = kRowBytes / (int)sizeof(T);
     constexpr int MI = BM / 32;  // 16-row fragments per wave
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
     constexpr int OFF_F = (BM + (MAIN ? BN : 0)) * kRowBytes;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sQ = smem + (PIPE ? kStages : 1) * STAGE;
+    char* sQ = smem + kStages * STAGE;
     float* sP = reinterpret_cast<float*>(smem);  // epilogue overlay: [2][BM][16]
 
     const int tid = threadIdx.x;
@@ -259,18 +261,19 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
             }
             glds16(f_ptr + k0, st + OFF_F);
         };
+        constexpr int DIST = kStages - 1;  // K-steps in flight ahead of the one being multiplied
         issue(0, 0);
-        if (nk > 1) issue(1, 1);
+        if (DIST > 1 && nk > 1) issue(1, 1);
         int buf = 0;
         for (int kt = 0; kt < nk; ++kt) {
-            // stage kt landed for this wave once at most the L loads of stage kt+1 are outstanding
-            if (kt + 1 < nk) {
+            // stage kt has landed for this wave once only the loads of the stages issued after it are outstanding
+            if (DIST > 1 && kt + 1 < nk) {
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __builtin_amdgcn_s_barrier();  // every wave's part of stage kt is in; stage kt-1 is fully read
-            if (kt + 2 < nk) issue(kt + 2, buf >= 1 ? buf - 1 : kStages - 1);  // refill the buffer read last step
+            if (kt + DIST < nk) issue(kt + DIST, buf >= 1 ? buf - 1 : kStages - 1);  // refill the buffer read last step
             compute(smem + buf * STAGE);
             buf = buf + 1 == kStages ? 0 : buf + 1;
         }
@@ -518,12 +521,12 @@ __global__ __launch_bounds__(256) void pack_factors_batched_kernel(const int64_t
     }
 }
 
-template <typename T, int BM, int BN, bool MAIN, bool PIPE>
+template <typename T, int BM, int BN, bool MAIN, int STG>
 int launch_tile(GemmParams p, hipStream_t stream) {
     p.tiles_m = (int)((p.M + BM - 1) / BM);
     p.tiles_n = MAIN ? (p.Nc + BN - 1) / BN : 1;
-    constexpr int lds = gemm_lds_bytes<BM, BN, T, MAIN, PIPE>();
-    auto kern = lora_gemm_kernel<T, BM, BN, MAIN, PIPE>;
+    constexpr int lds = gemm_lds_bytes<BM, BN, T, MAIN, STG>();
+    auto kern = lora_gemm_kernel<T, BM, BN, MAIN, STG>;
     if (lds > 48 * 1024) {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -544,18 +547,27 @@ int forced_tile() {  // tuning knob for tools/gemm_bench.py only
     return forced;
 }
 
-// Tile choice (measured on MI355X, tools/gemm_bench.py): the 128×128 tile wins once its grid fills at least
-// half the chip and the last column tile is not mostly padding; everything smaller or narrower runs 64×64
-// (two resident workgroups per CU, four times the workgroups).  128×64 never won and is not instantiated.
+// Tile and ring-depth choice, from tools/gemm_bench.py sweeps on MI355X (profiles/README.md):
+//  * occupancy beats prefetch depth: a 2-stage ring lets two 128×128 workgroups share a CU (78 KB LDS each) and
+//    is 25-35 % faster than the 3-stage ring at one workgroup per CU on every shape that fills the chip;
+//  * 128×128 once its grid has >= 128 tiles (and the last column tile is not mostly padding), else 64×64;
+//  * 64×64: 2 stages (3 workgroups per CU) when there are >= 512 tiles to overlap, 3 stages (deeper prefetch)
+//    for the small latency-bound grids.  128×64 never won and is not instantiated.
 template <typename T, bool MAIN>
 int launch_pipe(const GemmParams& p, hipStream_t stream) {
-    if (!MAIN) return launch_tile<T, 64, 64, false, true>(p, stream);
+    if (!MAIN) return launch_tile<T, 64, 64, false, 3>(p, stream);
     const int64_t tiles128 = ((p.M + 127) / 128) * ((p.Nc + 127) / 128);
+    const int64_t tiles64 = ((p.M + 63) / 64) * ((p.Nc + 63) / 64);
     const int padded = (p.Nc + 127) / 128 * 128;
-    bool big = tiles128 >= 128 && (padded - p.Nc) * 10 <= p.Nc;
+    bool big = tiles128 >= 128 && (padded - p.Nc) * 4 <= p.Nc;
+    bool deep = tiles64 < 512;
+    static const int stg_env = [] { const char* e = getenv("LORA_FORCE_STAGES"); return e ? atoi(e) : 0; }();
     if (forced_tile() == 0) big = true;
     if (forced_tile() == 2) big = false;
-    return big ? launch_tile<T, 128, 128, true, true>(p, stream) : launch_tile<T, 64, 64, true, true>(p, stream);
+    if (big) return stg_env == 3 ? launch_tile<T, 128, 128, true, 3>(p, stream) : launch_tile<T, 128, 128, true, 2>(p, stream);
+    if (stg_env == 2) deep = false;
+    if (stg_env == 3) deep = true;
+    return deep ? launch_tile<T, 64, 64, true, 3>(p, stream) : launch_tile<T, 64, 64, true, 2>(p, stream);
 }
 
 struct CallArgs {  // what an entry point knows
@@ -585,7 +597,7 @@ int launch_typed(const CallArgs& c, bool main_part, hipStream_t stream) {
         p.Am = c.Am; p.Bm = c.Bm; p.bias = c.bias; p.Fp = c.Fp; p.Q = c.Q; p.q_sn = c.q_sn; p.q_sj = c.q_sj;
         p.C = c.C; p.P = c.P; p.M = c.M; p.Kc = c.Kc; p.Nc = c.Nc; p.r = c.r; p.scale = c.scale;
         if ((c.Kc % BK) == 0) return main_part ? launch_pipe<T, true>(p, stream) : launch_pipe<T, false>(p, stream);
-        return main_part ? launch_tile<T, 64, 64, true, false>(p, stream) : launch_tile<T, 64, 64, false, false>(p, stream);
+        return main_part ? launch_tile<T, 64, 64, true, 0>(p, stream) : launch_tile<T, 64, 64, false, 0>(p, stream);
     }
     GenericParams g{};
     g.Am = c.Am; g.Bm = c.Bm; g.bias = c.bias; g.F = c.F; g.f_sr = c.f_sr; g.f_sk = c.f_sk; g.Q = c.Q;

@@ -7,7 +7,7 @@
 //     several independent loads are in flight; r×VEC fp32 accumulators stay in VGPRs; the P row is a
 //     broadcast load;
 //   - 256 threads cover ⌊256/CL⌋ rows per pass when the strip is narrower than the workgroup; the row
-//     groups are combined with LDS float adds;
+//     groups are combined through LDS (16-B writes, one summing thread per output);
 //   - the M range is cut into `n_blocks` row blocks; each block STORES its partial sums (plain 16-B-friendly
 //     stores, no global atomics: the outputs are only a few KB wide, and atomics from hundreds of
 //     workgroups onto so few cache lines serialise at the memory side);
@@ -94,32 +94,37 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(GradParams p) {
         }
     }
 
-    // combine the row groups: LDS image [j][c_local] (j-major), zero → ds_add → plain store
-    const int total = p.r * stripW;
-    for (int i = tid; i < total; i += 256) sred[i] = 0.f;
-    __syncthreads();
-    if (active) {
-#pragma unroll
-        for (int j = 0; j < RP; ++j) {
-            if (j < p.r) {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) atomicAdd(&sred[j * stripW + c_local + e], acc[j][e]);
-            }
-        }
-    }
-    __syncthreads();
+    // combine the row groups through LDS, four rank columns at a time: image [row group][jj][strip column],
+    // 16-B writes, then every output is summed over the row groups by one thread and stored (plain stores)
     float* G = q.G + (int64_t)blockIdx.y * p.part_stride;
-    if (q.out_kn) {
-        // gA[j, c0 + c]: every j row is a contiguous run of stripW floats
-        for (int i = tid; i < total; i += 256) {
-            const int j = i / stripW, c = i - j * stripW;
-            G[(int64_t)j * q.C + c0 + c] = p.scale * sred[i];
-        }
-    } else {
-        // gB[(c0 + c), j]: the whole strip block is one contiguous run of stripW·r floats
-        for (int i = tid; i < total; i += 256) {
-            const int c = i / p.r, j = i - c * p.r;
-            G[(int64_t)c0 * p.r + i] = p.scale * sred[j * stripW + c];
+    const int WS = CL * VEC;
+    const bool writer = rsub < rows_pp;
+#pragma unroll
+    for (int j0 = 0; j0 < RP; j0 += 4) {
+        if (j0 < p.r) {  // wave-uniform
+            __syncthreads();
+            if (writer) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int e = 0; e < VEC; e += 4)
+                        *reinterpret_cast<float4*>(&sred[(rsub * 4 + jj) * WS + c_local + e]) =
+                            float4{acc[j0 + jj][e], acc[j0 + jj][e + 1], acc[j0 + jj][e + 2], acc[j0 + jj][e + 3]};
+            }
+            __syncthreads();
+            for (int i = tid; i < 4 * stripW; i += 256) {
+                const int jj = i / stripW, c = i - jj * stripW;
+                const int j = j0 + jj;
+                if (j < p.r) {
+                    float sum = 0.f;
+                    for (int g = 0; g < rows_pp; ++g) sum += sred[(g * 4 + jj) * WS + c];
+                    sum *= p.scale;
+                    if (q.out_kn)
+                        G[(int64_t)j * q.C + c0 + c] = sum;       // gA[j, c]: contiguous runs per j
+                    else
+                        G[(int64_t)(c0 + c) * p.r + j] = sum;     // gB[c, j]
+                }
+            }
         }
     }
 }
@@ -178,8 +183,7 @@ int launch_grad(GradParams p, int n_blocks, hipStream_t stream) {
         return LORA_OK;
     }
     const int rp = p.r <= 4 ? 4 : (p.r <= 8 ? 8 : 16);
-    // LDS image r·stripW floats ≤ 32 KiB  ⇒  CL ≤ 8192 / (VEC·rp)
-    const int cl_cap = 8192 / (VEC * rp) < 256 ? 8192 / (VEC * rp) : 256;
+    const int cl_cap = 256;  // a strip is at most one workgroup wide
     int max_strips = 1, max_lds = 0;
     for (int i = 0; i < 2; ++i) {
         GradProblem& q = p.prob[i];
@@ -189,7 +193,7 @@ int launch_grad(GradParams p, int n_blocks, hipStream_t stream) {
         q.CL = (chunks + strips - 1) / strips;
         q.strips = strips;
         if (strips > max_strips) max_strips = strips;
-        const int lds = p.r * q.CL * VEC * 4;
+        const int lds = 256 * 4 * VEC * 4;  // [row groups][4][strip] floats, one 4-column slab at a time
         if (lds > max_lds) max_lds = lds;
     }
     dim3 grid(max_strips, n_blocks, 2);

@@ -113,9 +113,9 @@ class _LoraLinearFn(torch.autograd.Function):
             if sink is not None:
                 # trainer mode: row-block partials go straight into the model-wide partial slab; the trainer
                 # reduces the whole slab (= the RCCL buffer) in one launch after backward
-                ga_part, gb_part, stride, n_blocks, ran = sink
-                nat.lora_linear_bwd_params_partial(dy2, x2, t, u, ga_part, gb_part, stride, n_blocks, ctx.scale)
-                ran[0] += 1
+                n_blocks = sink.blocks_for(dy2.shape[0])
+                nat.lora_linear_bwd_params_partial(dy2, x2, t, u, sink.ga_part, sink.gb_part, sink.stride, n_blocks,
+                                                   ctx.scale)
             else:
                 g_down = torch.zeros_like(a)
                 g_up = torch.zeros_like(b)

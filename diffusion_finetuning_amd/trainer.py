@@ -49,7 +49,7 @@ class LoraSlab:
     GRAD_BLOCKS = 128
 
     def __init__(self, models: Sequence[nn.Module]):
-        self._ran = []
+        self._sinks = []
         self.layers: List[LoraInjectedLinear] = []
         self.model_ranges: List[Tuple[int, int]] = []
         for model in models:
@@ -86,11 +86,10 @@ class LoraSlab:
                 views[attr] = gv
                 self.offsets.append((off, n))
                 off += n
-            starts = {a: self.offsets[-2 + i][0] for i, a in enumerate(("lora_up", "lora_down"))}
-            ran = [0]
-            self._ran.append(ran)
-            layer.__dict__["_dfa_grad_sink"] = (self.partials[0, starts["lora_down"]:], self.partials[0, starts["lora_up"]:],
-                                                self.stride, self.GRAD_BLOCKS, ran)
+            up_off, down_off = self.offsets[-2][0], self.offsets[-1][0]
+            sink = GradSink(self.partials, up_off, down_off, down_off + self.offsets[-1][1], self.stride, self.GRAD_BLOCKS)
+            self._sinks.append(sink)
+            layer.__dict__["_dfa_grad_sink"] = sink
 
     def enable_packed(self, dtype: torch.dtype):
         """Allocates the packed-factor slab ([16,K] + [16,N] per layer in the compute dtype) and the device
@@ -126,21 +125,19 @@ class LoraSlab:
 
     def zero_grad(self):
         self.grads.zero_()
-        for ran in self._ran:
-            ran[0] = 0
+        for sink in self._sinks:
+            sink.ran = 0
 
     def check_all_layers_ran(self):
         """A layer that did not run backward in this pass still holds an older pass's partials: clear those
         slices before they are reduced (never the case for a UNet step)."""
-        for i, ran in enumerate(self._ran):
-            if ran[0] == 0:
-                a = self.offsets[2 * i][0]
-                b = self.offsets[2 * i + 1][0] + self.offsets[2 * i + 1][1]
-                self.partials[:, a:b].zero_()
-            elif ran[0] > 1:
+        for sink in self._sinks:
+            if sink.ran == 0:
+                sink.clear(0)
+            elif sink.ran > 1:
                 raise RuntimeError("a LoRA layer ran backward more than once in one pass (shared module?): "
                                    "the partial-sum layout holds one pass per layer")
-            ran[0] = 0
+            sink.ran = 0
 
     def reduce_range(self, a: int, b: int):
         """grads[a:b] += Σ_blocks partials[:, a:b] (block order, deterministic)."""
@@ -161,6 +158,33 @@ class LoraSlab:
             return (0, 0)
         assert idx == list(range(idx[0], idx[-1] + 1)), "layers under the module are not contiguous in the slab"
         return (self.offsets[2 * idx[0]][0], self.offsets[2 * idx[-1] + 1][0] + self.offsets[2 * idx[-1] + 1][1])
+
+
+class GradSink:
+    """Where one layer's factor-gradient kernel stores its row-block partial sums inside the model-wide
+    [GRAD_BLOCKS][slab] buffer.  The number of row blocks follows M (≈128 rows per block, so small layers do not
+    write — and the fold does not read — mostly-empty blocks); blocks a layer stops using are zeroed once."""
+
+    def __init__(self, partials, up_off, down_off, end, stride, max_blocks):
+        self.partials, self.begin, self.end = partials, up_off, end
+        self.ga_part = partials[0, down_off:]
+        self.gb_part = partials[0, up_off:]
+        self.stride, self.max_blocks = stride, max_blocks
+        self.used = 0   # blocks holding data from the last pass
+        self.ran = 0
+
+    def blocks_for(self, M: int) -> int:
+        nb = max(min(4, self.max_blocks), min(self.max_blocks, M // 32))
+        if nb < self.used:
+            self.partials[nb:self.used, self.begin:self.end].zero_()
+        self.used = nb
+        self.ran += 1
+        return nb
+
+    def clear(self, keep: int):
+        if self.used > keep:
+            self.partials[keep:self.used, self.begin:self.end].zero_()
+            self.used = keep
 
 
 class FusedClipAdamW:
@@ -207,9 +231,12 @@ class SlabExchange:
     `prepare(a, b)` (optional) is called for every slab range right before it is sent — the trainer uses it to
     fold the row-block partial sums of that range into the gradient slab — and also when world == 1."""
 
-    def __init__(self, grads: torch.Tensor, numel: int, process_group=None, prepare=None):
+    def __init__(self, grads: torch.Tensor, numel: int, process_group=None, prepare=None, always_reduce=False):
         self.grads, self.numel, self.pg, self.prepare = grads, numel, process_group, prepare
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        # always_reduce: run the bucketed all-reduce path even on a 1-rank group (used to test the RCCL path
+        # on a single GPU)
+        self.active = self.world > 1 or (always_reduce and dist.is_available() and dist.is_initialized())
         self.early_range: Optional[Tuple[int, int]] = None
         self._armed = False
         self._early_sent = False
@@ -217,7 +244,7 @@ class SlabExchange:
 
     def arm(self):
         """Call before each backward pass; launch_early() then fires at most once."""
-        self._armed = self.world > 1 and self.early_range is not None
+        self._armed = self.active and self.early_range is not None
         self._early_sent = False
 
     def _send(self, a: int, b: int):
@@ -225,7 +252,7 @@ class SlabExchange:
             return
         if self.prepare is not None:
             self.prepare(a, b)
-        if self.world > 1:
+        if self.active:
             self._pending.append(dist.all_reduce(self.grads[a:b], group=self.pg, async_op=True))
 
     def launch_early(self):
@@ -257,7 +284,7 @@ class LoraTrainer:
 
     def __init__(self, unet: nn.Module, text_encoder: Optional[nn.Module] = None, lr=1e-4, lr_text=5e-6,
                  weight_decay=1e-2, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0, loss_scale: Optional[float] = None,
-                 v_prediction=False, process_group=None):
+                 v_prediction=False, process_group=None, always_reduce=False):
         self.unet, self.text_encoder = unet, text_encoder
         models = [unet] + ([text_encoder] if text_encoder is not None and lora_layers(text_encoder) else [])
         self.slab = LoraSlab(models)
@@ -273,8 +300,9 @@ class LoraTrainer:
         self.sqrt_acp, self.sqrt_1macp = ddpm_tables(device=self.device)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
-        self.exchange = SlabExchange(self.slab.grads, self.slab.numel, process_group, prepare=self.slab.reduce_range)
-        if self.world > 1:
+        self.exchange = SlabExchange(self.slab.grads, self.slab.numel, process_group, prepare=self.slab.reduce_range,
+                                     always_reduce=always_reduce)
+        if self.exchange.active:
             self._broadcast_initial_state()
             self._install_bucket_hook()
 

@@ -402,3 +402,31 @@ def test_full_size_properties_cfg2():
         nat.lora_linear_bwd_params(dy[:h], x[:h], T[:h], U[:h], ga2, gb2, 1.0)
         nat.lora_linear_bwd_params(dy[h:], x[h:], T[h:], U[h:], ga2, gb2, 1.0)
         assert ((ga - ga2).norm() / ga.norm()).item() < 1e-5 and ((gb - gb2).norm() / gb.norm()).item() < 1e-5
+
+
+def test_rccl_bucketed_exchange_single_rank(golden_trajectory, tiny_unet_factory, relerr):
+    """The multi-GPU code path (broadcast, early [up|mid] bucket launched from the mid-block backward hook, RCCL
+    all-reduce of slab ranges, partial-sum folding per range) on ONE GPU: a 1-rank NCCL(=RCCL) group must reproduce
+    the reference trajectory exactly like the plain path does."""
+    import os
+    import torch.distributed as dist
+
+    t, meta = golden_trajectory
+    cfg = json.loads(meta["plain"])
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        unet = tiny_unet_factory(seed=cfg["unet_seed"]).to(DEV)
+        params, _ = dfa.inject_trainable_lora(unet, r=4)
+        _warm(list(itertools.chain(*params)), cfg["warm_seed"], cfg["warm_std"])
+        trainer = tr.LoraTrainer(unet, lr=cfg["lr"], always_reduce=True)
+        assert trainer.exchange.active and trainer.exchange.early_range is not None
+        a, b = trainer.exchange.early_range
+        assert 0 < a < b == trainer.slab.numel  # [down | up | mid]: the early bucket is the tail
+        for step in range(cfg["steps"]):
+            latents, noise, ts, ctx = orc.synthetic_batch(step, cfg["batch"], cfg["latent_hw"], cfg["ctx_len"], cfg["ctx_dim"])
+            trainer.step(latents.to(DEV), noise.to(DEV), ts.to(DEV), ctx.to(DEV))
+        assert relerr(tr.flat_lora_state(unet), t["plain.final"]) < 1e-3
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,69 @@
+"""Turns rocprofv3 CSV output of `bench.py` into the small summaries committed under profiles/.
+
+  python tools/summarize_profile.py trace <kernel_trace.csv> <warmup_steps> <out.csv>
+      per-kernel stats of the TIMED region only (from the (warmup+1)-th add_noise dispatch on), so one-time
+      MIOpen solver searches during warm-up do not pollute the table.
+  python tools/summarize_profile.py pmc <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+      average FETCH_SIZE / WRITE_SIZE (KB) per dispatch for the hot-path kernels, and the corrected traffic
+      (2·FETCH_SIZE + WRITE_SIZE)·1024 bytes (MI355X_MICROARCH.md §HBM: FETCH_SIZE reads ½ on gfx950).
+"""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def short(name):
+    m = re.search(r"(lora_\w+kernel|ddpm_mse_kernel|add_noise_kernel|reduce_partials_kernel|pack_factors\w*|grad_sqnorm_kernel|adamw_kernel)", name)
+    if not m:
+        return name[:80]
+    t = re.search(r"I(DF16_|DF16b|f)(?:Li(\d+)E)?(?:Li(\d+)E)?(?:Lb(\d)E)?(?:Lb(\d)E)?", name)
+    return m.group(1) + ("<" + ",".join(x for x in t.groups() if x) + ">" if t else "")
+
+
+def trace(path, warmup, out):
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    starts = [int(r["Start_Timestamp"]) for r in rows if "add_noise_kernel" in r["Kernel_Name"]]
+    t0 = starts[warmup]
+    steps = len(starts) - warmup
+    agg = collections.defaultdict(list)
+    for r in rows:
+        if int(r["Start_Timestamp"]) >= t0:
+            agg[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    total = sum(sum(v) for v in agg.values())
+    with open(out, "w") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls_per_step", "avg_us", "min_us", "max_us", "ms_per_step", "pct_of_gpu_time"])
+        for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+            w.writerow([k, f"{len(v) / steps:.1f}", f"{sum(v) / len(v) / 1e3:.2f}", f"{min(v) / 1e3:.2f}", f"{max(v) / 1e3:.2f}",
+                        f"{sum(v) / steps / 1e6:.3f}", f"{100 * sum(v) / total:.2f}"])
+        w.writerow(["TOTAL (timed region, %d steps)" % steps, "", "", "", "", f"{total / steps / 1e6:.3f}", "100"])
+    print(open(out).read())
+
+
+def pmc(fetch, write, out):
+    def load(path, counter):
+        agg = collections.defaultdict(lambda: [0, 0.0])
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == counter and ("lora_" in r["Kernel_Name"] or "ddpm" in r["Kernel_Name"]):
+                a = agg[short(r["Kernel_Name"])]
+                a[0] += 1
+                a[1] += float(r["Counter_Value"])
+        return agg
+    f, w = load(fetch, "FETCH_SIZE"), load(write, "WRITE_SIZE")
+    res = {}
+    for k in f:
+        fk, wk = f[k][1] / f[k][0], w[k][1] / max(1, w[k][0])
+        res[k] = {"dispatches": f[k][0], "FETCH_SIZE_KB_avg": fk, "WRITE_SIZE_KB_avg": wk,
+                  "traffic_bytes_per_launch": (2 * fk + wk) * 1024}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "trace":
+        trace(sys.argv[2], int(sys.argv[3]), sys.argv[4])
+    else:
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
