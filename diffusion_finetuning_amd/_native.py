@@ -36,8 +36,8 @@ SIGNATURES = {
     "lora_status_string": (ctypes.c_char_p, [_i32]),
     "lora_pack_factors": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "lora_pack_factors_batched": (_i32, [_vp, _i32, _i32, _vp, _vp, _i32, _vp]),
-    "lora_linear_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
-    "lora_linear_bwd_input": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "lora_linear_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "lora_linear_bwd_input": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
     "lora_linear_bwd_params": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
     "lora_reduce_partials": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp]),
     "ddpm_mse_fwd_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i64, _i64, _f32, _f32, _vp, _vp, _vp, _i32, _vp]),
@@ -119,17 +119,18 @@ def _require_device(*tensors) -> None:
 
 
 def lora_pack_factors(a, b, dtype: torch.dtype):
-    """a [r,K], b [N,r] fp32 → (A16 [16,K], Bt16 [16,N]) in `dtype`; (None, None) for r > 16."""
+    """a [r,K], b [N,r] fp32 → (Apack [2,16·K], Bpack [2,16·N]) in `dtype` (both orientations, see lora_hip.h);
+    (None, None) for r > 16."""
     _require_device(a, b)
     r, K = a.shape
     N = b.shape[0]
     if r > 16:
         return None, None
-    a16 = torch.empty((16, K), dtype=dtype, device=a.device)
-    bt16 = torch.empty((16, N), dtype=dtype, device=a.device)
-    _check(lib().lora_pack_factors(_ptr(a), _ptr(b), _ptr(a16), _ptr(bt16), K, N, r, dtype_code(dtype), _stream(a)),
+    apack = torch.empty(32 * K, dtype=dtype, device=a.device)
+    bpack = torch.empty(32 * N, dtype=dtype, device=a.device)
+    _check(lib().lora_pack_factors(_ptr(a), _ptr(b), _ptr(apack), _ptr(bpack), K, N, r, dtype_code(dtype), _stream(a)),
            "lora_pack_factors")
-    return a16, bt16
+    return apack, bpack
 
 
 def lora_pack_factors_batched(table, n_layers: int, max_len: int, params, packed) -> None:
@@ -138,37 +139,37 @@ def lora_pack_factors_batched(table, n_layers: int, max_len: int, params, packed
                                            dtype_code(packed.dtype), _stream(params)), "lora_pack_factors_batched")
 
 
-def lora_linear_fwd(x2, w, bias, a, b, scale: float, a16=None):
-    """x2 [M,K], w [N,K], bias [N]|None (dtype of x2); a [r,K], b [N,r] fp32 masters; a16 packed A
+def lora_linear_fwd(x2, w, bias, a, b, scale: float, packs=None):
+    """x2 [M,K], w [N,K], bias [N]|None (dtype of x2); a [r,K], b [N,r] fp32 masters; packs = (Apack, Bpack)
     (made here when not given). Returns (y [M,N], T [M,r] fp32)."""
-    _require_device(x2, w, bias, a, b, a16)
+    _require_device(x2, w, bias, a, b)
     M, K = x2.shape
     N, r = b.shape
-    if a16 is None and r <= 16:
-        a16, _ = lora_pack_factors(a, b, x2.dtype)
+    if packs is None:
+        packs = lora_pack_factors(a, b, x2.dtype)
     y = torch.empty((M, N), dtype=x2.dtype, device=x2.device)
     t = torch.empty((M, r), dtype=torch.float32, device=x2.device)
     _check(
-        lib().lora_linear_fwd(_ptr(x2), _ptr(w), _ptr(bias), _ptr(a), _ptr(b), _ptr(a16), _ptr(y), _ptr(t), M, K, N,
-                              r, float(scale), dtype_code(x2.dtype), _stream(x2)),
+        lib().lora_linear_fwd(_ptr(x2), _ptr(w), _ptr(bias), _ptr(a), _ptr(b), _ptr(packs[0]), _ptr(packs[1]), _ptr(y),
+                              _ptr(t), M, K, N, r, float(scale), dtype_code(x2.dtype), _stream(x2)),
         "lora_linear_fwd",
     )
     return y, t
 
 
-def lora_linear_bwd_input(dy2, wt, a, b, scale: float, need_dx: bool, bt16=None):
-    """dy2 [M,N]; wt [K,N] (= Wᵀ) or None when need_dx is False; bt16 packed Bᵀ (made here when not given).
+def lora_linear_bwd_input(dy2, wt, a, b, scale: float, need_dx: bool, packs=None):
+    """dy2 [M,N]; wt [K,N] (= Wᵀ) or None when need_dx is False; packs = (Apack, Bpack) (made here when not given).
     Returns (dx [M,K]|None, U [M,r] fp32)."""
-    _require_device(dy2, wt, a, b, bt16)
+    _require_device(dy2, wt, a, b)
     M, N = dy2.shape
     r, K = a.shape
-    if bt16 is None and r <= 16:
-        _, bt16 = lora_pack_factors(a, b, dy2.dtype)
+    if packs is None:
+        packs = lora_pack_factors(a, b, dy2.dtype)
     dx = torch.empty((M, K), dtype=dy2.dtype, device=dy2.device) if need_dx else None
     u = torch.empty((M, r), dtype=torch.float32, device=dy2.device)
     _check(
-        lib().lora_linear_bwd_input(_ptr(dy2), _ptr(wt), _ptr(a), _ptr(b), _ptr(bt16), _ptr(dx), _ptr(u), M, K, N, r,
-                                    float(scale), dtype_code(dy2.dtype), _stream(dy2)),
+        lib().lora_linear_bwd_input(_ptr(dy2), _ptr(wt), _ptr(a), _ptr(b), _ptr(packs[0]), _ptr(packs[1]), _ptr(dx),
+                                    _ptr(u), M, K, N, r, float(scale), dtype_code(dy2.dtype), _stream(dy2)),
         "lora_linear_bwd_input",
     )
     return dx, u

@@ -35,9 +35,8 @@ struct GemmParams {
     const void* Am;
     const void* Bm;
     const void* bias;
-    const void* Fp;  // packed factor [16, Kc] (dtype T)
-    const float* Q;
-    int64_t q_sn, q_sj;  // Q[n,j]  at Q[n*q_sn + j*q_sj]
+    const void* Fp;  // packed main-loop factor   [16, Kc] (dtype T), rows >= r zero
+    const void* Qp;  // packed epilogue factor    [Nc, 16] (dtype T), columns >= r zero
     void* C;
     float* P;
     int64_t M;
@@ -156,15 +155,15 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
     }
     const T* f_ptr = Fg + (int64_t)(ld_row & 15) * p.Kc;
 
-    // ---- Q tile (epilogue factor), staged once -------------------------------------------
+    // ---- Q tile (epilogue factor): BN packed rows of 16 values, 16-B chunks, rows clamped at the edge -----
     if constexpr (MAIN) {
-        T* q = reinterpret_cast<T*>(sQ);
-        for (int idx = tid; idx < BN * kRP; idx += 256) {
-            const int n = idx >> 4, j = idx & 15;
+        constexpr int CPRQ = kRP * (int)sizeof(T) / 16;  // chunks per packed row (2 for 16-bit, 4 for f32)
+        const T* Qg = static_cast<const T*>(p.Qp);
+        for (int idx = tid; idx < BN * CPRQ; idx += 256) {
+            const int n = idx / CPRQ, ch = idx - n * CPRQ;
             const int nn = n0 + n < p.Nc ? n0 + n : p.Nc - 1;
-            const int jj = j < p.r ? j : p.r - 1;
-            const float v = p.Q[(int64_t)nn * p.q_sn + jj * p.q_sj];  // unconditional, clamped
-            q[idx] = from_f32<T>((j < p.r && n0 + n < p.Nc) ? v : 0.f);
+            *reinterpret_cast<Chunk<T>*>(sQ + idx * 16) =
+                *reinterpret_cast<const Chunk<T>*>(Qg + (int64_t)nn * kRP + ch * VEC);
         }
     }
 
@@ -485,40 +484,40 @@ __global__ void lora_gemm_generic_kernel(GenericParams p) {
     static_cast<T*>(p.C)[idx] = from_f32<T>(s);
 }
 
-// packed factor: dst[j, k] = (T) src[j*sr + k*sk] for j < r, 0 for r <= j < 16
+// Packed factors, both orientations per factor (dtype T, rank padded to 16 with zeros):
+//   Apack = [ A16 [16,K] : A16[j,k] = A[j,k] | At16 [K,16] : At16[k,j] = A[j,k] ]      (32·K elements)
+//   Bpack = [ Bt16[16,N] : Bt16[j,n] = B[n,j] | B16 [N,16] : B16[n,j] = B[n,j] ]       (32·N elements)
+// The [16,len] halves are the main-loop factor tiles (F), the [len,16] halves the epilogue factors (Q).
 template <typename T>
-__global__ __launch_bounds__(256) void pack_factor_kernel(const float* A, const float* B, T* A16, T* Bt16, int K,
-                                                          int N, int r) {
-    const int which = blockIdx.y;  // 0: A16[j,k] = A[j*K + k]   1: Bt16[j,n] = B[n*r + j]
+__device__ __forceinline__ void pack_one(const float* A, const float* B, T* Apack, T* Bpack, int K, int N, int r,
+                                         int which, int start, int step) {
     const int len = which == 0 ? K : N;
-    T* dst = which == 0 ? A16 : Bt16;
-    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < kRP * len; idx += gridDim.x * 256) {
+    T* dst = which == 0 ? Apack : Bpack;
+    for (int idx = start; idx < kRP * len; idx += step) {
         const int j = idx / len, c = idx - j * len;
         const int jj = j < r ? j : r - 1;
         const float v = which == 0 ? A[(int64_t)jj * K + c] : B[(int64_t)c * r + jj];
-        dst[idx] = from_f32<T>(j < r ? v : 0.f);
+        const T t = from_f32<T>(j < r ? v : 0.f);
+        dst[idx] = t;                                   // [16, len]
+        dst[(int64_t)kRP * len + (int64_t)c * kRP + j] = t;  // [len, 16]
     }
 }
+template <typename T>
+__global__ __launch_bounds__(256) void pack_factor_kernel(const float* A, const float* B, T* Apack, T* Bpack, int K,
+                                                          int N, int r) {
+    pack_one<T>(A, B, Apack, Bpack, K, N, r, blockIdx.y, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+}
 
-// All layers of a slab in one launch.  table[l] = {a_off, b_off, K, N, r, a16_off, bt16_off, 0}: element
-// offsets of A[r,K] / B[N,r] inside `params` (fp32) and of the packed outputs inside `packed` (T).
+// All layers of a slab in one launch.  table[l] = {a_off, b_off, K, N, r, apack_off, bpack_off, 0}: element
+// offsets of A[r,K] / B[N,r] inside `params` (fp32) and of Apack / Bpack inside `packed` (T).
 template <typename T>
 __global__ __launch_bounds__(256) void pack_factors_batched_kernel(const int64_t* table, const float* params,
                                                                    T* packed) {
     const int64_t* e = table + (int64_t)(blockIdx.y >> 1) * 8;
-    const int which = blockIdx.y & 1;
     const int K = (int)e[2], N = (int)e[3], r = (int)e[4];
     if (r > kRP) return;
-    const float* A = params + e[0];
-    const float* B = params + e[1];
-    const int len = which == 0 ? K : N;
-    T* dst = packed + (which == 0 ? e[5] : e[6]);
-    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < kRP * len; idx += gridDim.x * 256) {
-        const int j = idx / len, c = idx - j * len;
-        const int jj = j < r ? j : r - 1;
-        const float v = which == 0 ? A[(int64_t)jj * K + c] : B[(int64_t)c * r + jj];
-        dst[idx] = from_f32<T>(j < r ? v : 0.f);
-    }
+    pack_one<T>(params + e[0], params + e[1], packed + e[5], packed + e[6], K, N, r, blockIdx.y & 1,
+                blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
 template <typename T, int BM, int BN, bool MAIN, int STG>
@@ -574,8 +573,9 @@ struct CallArgs {  // what an entry point knows
     const void* Am;
     const void* Bm;
     const void* bias;
-    const void* Fp;      // packed factor [16,Kc] (T)
-    const float* F;      // fp32 master of the same factor, strided (generic path)
+    const void* Fp;      // packed main-loop factor [16,Kc] (T)
+    const void* Qp;      // packed epilogue factor [Nc,16] (T)
+    const float* F;      // fp32 master of the main-loop factor, strided (generic path)
     int64_t f_sr, f_sk;
     const float* Q;
     int64_t q_sn, q_sj;
@@ -590,11 +590,12 @@ template <typename T>
 int launch_typed(const CallArgs& c, bool main_part, hipStream_t stream) {
     constexpr int VEC = ElemTraits<T>::kVec;
     constexpr int BK = kRowBytes / (int)sizeof(T);
-    const bool fast = c.r <= kRP && c.Fp != nullptr && (c.Kc % VEC) == 0 && aligned16(c.Am) && aligned16(c.Fp) &&
+    const bool fast = c.r <= kRP && c.Fp != nullptr && c.Qp != nullptr && (c.Kc % VEC) == 0 && aligned16(c.Am) &&
+                      aligned16(c.Fp) && aligned16(c.Qp) &&
                       (!main_part || ((c.Nc % VEC) == 0 && aligned16(c.Bm) && aligned16(c.C)));
     if (fast) {
         GemmParams p{};
-        p.Am = c.Am; p.Bm = c.Bm; p.bias = c.bias; p.Fp = c.Fp; p.Q = c.Q; p.q_sn = c.q_sn; p.q_sj = c.q_sj;
+        p.Am = c.Am; p.Bm = c.Bm; p.bias = c.bias; p.Fp = c.Fp; p.Qp = c.Qp;
         p.C = c.C; p.P = c.P; p.M = c.M; p.Kc = c.Kc; p.Nc = c.Nc; p.r = c.r; p.scale = c.scale;
         if ((c.Kc % BK) == 0) return main_part ? launch_pipe<T, true>(p, stream) : launch_pipe<T, false>(p, stream);
         return main_part ? launch_tile<T, 64, 64, true, 0>(p, stream) : launch_tile<T, 64, 64, false, 0>(p, stream);
@@ -636,8 +637,10 @@ double esize(int dtype) { return dtype == LORA_F32 ? 4.0 : 2.0; }
 
 }  // namespace
 
-extern "C" int lora_pack_factors(const float* A, const float* B, void* A16, void* Bt16, int K, int N, int r,
+extern "C" int lora_pack_factors(const float* A, const float* B, void* Apack, void* Bpack, int K, int N, int r,
                                  int dtype, void* stream) {
+    void* A16 = Apack;
+    void* Bt16 = Bpack;
     if (!A || !B || !A16 || !Bt16 || K < 1 || N < 1) return LORA_E_BADARG;
     if (r < 1 || r > (K < N ? K : N)) return LORA_E_RANK;
     if (r > kRP) return LORA_OK;  // large ranks run on the generic kernels, which read the fp32 masters
@@ -688,15 +691,18 @@ extern "C" int lora_pack_factors_batched(const int64_t* table, int n_layers, int
 }
 
 extern "C" int lora_linear_fwd(const void* X, const void* W, const void* bias, const float* A, const float* B,
-                               const void* A16, void* Y, float* T_out, int64_t M, int K, int N, int r, float scale,
-                               int dtype, void* stream) {
+                               const void* Apack, const void* Bpack, void* Y, float* T_out, int64_t M, int K, int N,
+                               int r, float scale, int dtype, void* stream) {
     const int st = check_common(M, K, N, r, dtype);
     if (st != LORA_OK) return st;
     if (M == 0) return LORA_OK;  // empty batch: nothing to do (pointers may be null)
     if (!X || !W || !A || !B || !Y || !T_out) return LORA_E_BADARG;
     CallArgs c{};
     c.Am = X; c.Bm = W; c.bias = bias;
-    c.Fp = A16; c.F = A; c.f_sr = K; c.f_sk = 1;   // F[j,k] = A[j,k]
+    const size_t es = dtype == LORA_F32 ? 4 : 2;
+    c.Fp = Apack;                                                              // A16  [16,K]
+    c.Qp = Bpack ? static_cast<const char*>(Bpack) + (size_t)kRP * N * es : nullptr;  // B16  [N,16]
+    c.F = A; c.f_sr = K; c.f_sk = 1;               // F[j,k] = A[j,k]
     c.Q = B; c.q_sn = r; c.q_sj = 1;               // Q[n,j] = B[n,j]
     c.C = Y; c.P = T_out;
     c.M = M; c.Kc = K; c.Nc = N; c.r = r; c.scale = scale;
@@ -708,8 +714,8 @@ extern "C" int lora_linear_fwd(const void* X, const void* W, const void* bias, c
 }
 
 extern "C" int lora_linear_bwd_input(const void* dY, const void* Wt, const float* A, const float* B,
-                                     const void* Bt16, void* dX, float* U_out, int64_t M, int K, int N, int r,
-                                     float scale, int dtype, void* stream) {
+                                     const void* Apack, const void* Bpack, void* dX, float* U_out, int64_t M, int K,
+                                     int N, int r, float scale, int dtype, void* stream) {
     const int st = check_common(M, K, N, r, dtype);
     if (st != LORA_OK) return st;
     if (M == 0) return LORA_OK;
@@ -717,7 +723,10 @@ extern "C" int lora_linear_bwd_input(const void* dY, const void* Wt, const float
     if (dX && !Wt) return LORA_E_BADARG;
     CallArgs c{};
     c.Am = dY; c.Bm = Wt; c.bias = nullptr;
-    c.Fp = Bt16; c.F = B; c.f_sr = 1; c.f_sk = r;  // F[j,n] = B[n,j]
+    const size_t es = dtype == LORA_F32 ? 4 : 2;
+    c.Fp = Bpack;                                                              // Bt16 [16,N]
+    c.Qp = Apack ? static_cast<const char*>(Apack) + (size_t)kRP * K * es : nullptr;  // At16 [K,16]
+    c.F = B; c.f_sr = 1; c.f_sk = r;               // F[j,n] = B[n,j]
     c.Q = A; c.q_sn = 1; c.q_sj = K;               // Q[k,j] = A[j,k]
     c.C = dX; c.P = U_out;
     c.M = M; c.Kc = N; c.Nc = K; c.r = r; c.scale = scale;

@@ -80,10 +80,10 @@ class _LoraLinearFn(torch.autograd.Function):
         b = _as_f32(up)
         # packed factors: the trainer keeps them current for the whole slab (one launch per optimizer step);
         # otherwise they are cast here, once per call, like autocast casts lora_down/lora_up in the reference
-        a16, bt16 = packed if packed is not None else nat.lora_pack_factors(a, b, w.dtype)
-        y2, t = nat.lora_linear_fwd(x2, w, bias, a, b, scale, a16)
+        packs = packed if packed is not None else nat.lora_pack_factors(a, b, w.dtype)
+        y2, t = nat.lora_linear_fwd(x2, w, bias, a, b, scale, packs)
         ctx.save_for_backward(x2, a, b, t)
-        ctx.bt16 = bt16
+        ctx.packs = packs
         ctx.wt = wt
         ctx.scale = float(scale)
         ctx.x_shape = x.shape
@@ -106,7 +106,7 @@ class _LoraLinearFn(torch.autograd.Function):
             dy2 = dy2.contiguous()
         if need_dx and ctx.wt is None:
             raise RuntimeError("lora_linear backward: Wᵀ operand was not prepared in forward")
-        dx2, u = nat.lora_linear_bwd_input(dy2, ctx.wt if need_dx else None, a, b, ctx.scale, need_dx, ctx.bt16)
+        dx2, u = nat.lora_linear_bwd_input(dy2, ctx.wt if need_dx else None, a, b, ctx.scale, need_dx, ctx.packs)
         g_down = g_up = None
         if need_factors:
             sink = ctx.grad_sink

@@ -92,8 +92,9 @@ class LoraSlab:
             layer.__dict__["_dfa_grad_sink"] = sink
 
     def enable_packed(self, dtype: torch.dtype):
-        """Allocates the packed-factor slab ([16,K] + [16,N] per layer in the compute dtype) and the device
-        table for the one-launch re-pack; each layer gets `_dfa_packed = (A16, Bt16)` views."""
+        """Allocates the packed-factor slab (Apack 32·K + Bpack 32·N per layer in the compute dtype, both
+        orientations: lora_hip.h) and the device table for the one-launch re-pack; each layer gets
+        `_dfa_packed = (Apack, Bpack)` views."""
         rows = []
         off = 0
         self._packed_layers = []
@@ -103,9 +104,9 @@ class LoraSlab:
             if r > 16:
                 continue
             up_off, down_off = self.offsets[2 * i][0], self.offsets[2 * i + 1][0]
-            rows.append([down_off, up_off, K, N, r, off, off + 16 * K, 0])
+            rows.append([down_off, up_off, K, N, r, off, off + 32 * K, 0])
             self._packed_layers.append((layer, off, K, N))
-            off += 16 * (K + N)
+            off += 32 * (K + N)
         if not rows:
             self.packed = None
             return
@@ -113,8 +114,7 @@ class LoraSlab:
         self._pack_table = torch.tensor(rows, dtype=torch.int64, device=self.params.device)
         self._pack_maxlen = max(max(r_[2], r_[3]) for r_ in rows)
         for layer, o, K, N in self._packed_layers:
-            layer.__dict__["_dfa_packed"] = (self.packed[o:o + 16 * K].view(16, K),
-                                             self.packed[o + 16 * K:o + 16 * (K + N)].view(16, N))
+            layer.__dict__["_dfa_packed"] = (self.packed[o:o + 32 * K], self.packed[o + 32 * K:o + 32 * (K + N)])
         self.repack()
 
     def repack(self):

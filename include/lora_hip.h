@@ -49,17 +49,19 @@ int lora_version(void);
 const char* lora_status_string(int status);
 
 /*
- * Packed rank-r factors.  The fused kernels stream the factor that is contracted in their main loop as a
- * 16-row operand tile in the compute dtype (rows >= r are zero):
- *     A16 [16,K]  : A16[j,k]  = (dtype) A[j,k]      — forward  (T = X·Aᵀ)
- *     Bt16[16,N]  : Bt16[j,n] = (dtype) B[n,j]      — backward (U = dY·B)
- * i.e. the same cast of lora_down / lora_up to the compute dtype the reference gets from autocast on
- * lora.py:50.  Re-pack whenever A or B changed (once per optimizer step).  The batched form packs every
- * layer of a flat parameter slab in ONE launch: table[l] = {a_off, b_off, K, N, r, a16_off, bt16_off, 0}
- * (int64, device memory; element offsets into `params` resp. `packed`), max_len = max over layers of max(K,N).
+ * Packed rank-r factors: the compute-dtype copies of lora_down / lora_up the fused kernels stream, rank padded
+ * to 16 with zeros, BOTH orientations per factor so that each is a plain row-major operand tile:
+ *     Apack (32·K elements) = [ A16 [16,K] : A16[j,k]  = A[j,k] | At16[K,16] : At16[k,j] = A[j,k] ]
+ *     Bpack (32·N elements) = [ Bt16[16,N] : Bt16[j,n] = B[n,j] | B16 [N,16] : B16[n,j]  = B[n,j] ]
+ * The [16,len] halves are the main-loop factors (forward T = X·Aᵀ uses A16, backward U = dY·B uses Bt16), the
+ * [len,16] halves the epilogue factors (forward B16, backward At16).  This is the same cast of
+ * lora_down / lora_up to the compute dtype that autocast applies on lora.py:50 in the reference.  Re-pack
+ * whenever A or B changed (once per optimizer step).  The batched form packs every layer of a flat parameter
+ * slab in ONE launch: table[l] = {a_off, b_off, K, N, r, apack_off, bpack_off, 0} (int64, device memory;
+ * element offsets into `params` resp. `packed`), max_len = max over layers of max(K,N).
  * For r > 16 nothing is packed (those ranks run on the shape-agnostic kernels that read the fp32 masters).
  */
-int lora_pack_factors(const float* A, const float* B, void* A16, void* Bt16, int K, int N, int r,
+int lora_pack_factors(const float* A, const float* B, void* Apack, void* Bpack, int K, int N, int r,
                       int dtype, void* stream);
 int lora_pack_factors_batched(const int64_t* table, int n_layers, int max_len, const float* params,
                               void* packed, int dtype, void* stream);
@@ -68,11 +70,11 @@ int lora_pack_factors_batched(const int64_t* table, int n_layers, int max_len, c
  * Forward of LoraInjectedLinear.forward — lora_diffusion/lora.py:49-50
  *     Y = X·Wᵀ + b + s·((X·Aᵀ)·Bᵀ)
  * replaces F.linear ×3 + mul + add (5 launches + the [M,N] LoRA temporary) with one kernel.
- * A, B: fp32 masters; A16: packed A (nullable → shape-agnostic slow path).
+ * A, B: fp32 masters; Apack, Bpack: their packed forms (both nullable → shape-agnostic slow path).
  * T_out receives T = X·Aᵀ [M,r] fp32 for the backward.
  */
 int lora_linear_fwd(const void* X, const void* W, const void* bias /* nullable */,
-                    const float* A, const float* B, const void* A16 /* nullable */, void* Y,
+                    const float* A, const float* B, const void* Apack, const void* Bpack, void* Y,
                     float* T_out, int64_t M, int K, int N, int r, float scale, int dtype,
                     void* stream);
 
@@ -83,11 +85,10 @@ int lora_linear_fwd(const void* X, const void* W, const void* bias /* nullable *
  *     dX = dY·W + s·U·A                 [M,K]  (skipped when dX == NULL: attn2 to_k/to_v with a
  *                                               frozen text encoder need no input gradient)
  * Wt is the frozen weight stored TRANSPOSED, Wt[K,N] = Wᵀ, so that the contraction index n is
- * contiguous for both operands (the caller caches Wt once per frozen layer).  Bt16: packed Bᵀ
- * (nullable → shape-agnostic slow path).
+ * contiguous for both operands (the caller caches Wt once per frozen layer).  Apack, Bpack as above.
  */
 int lora_linear_bwd_input(const void* dY, const void* Wt, const float* A, const float* B,
-                          const void* Bt16 /* nullable */, void* dX /* nullable */, float* U_out,
+                          const void* Apack, const void* Bpack, void* dX /* nullable */, float* U_out,
                           int64_t M, int K, int N, int r, float scale, int dtype, void* stream);
 
 /*

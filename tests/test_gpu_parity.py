@@ -430,3 +430,78 @@ def test_rccl_bucketed_exchange_single_rank(golden_trajectory, tiny_unet_factory
         assert relerr(tr.flat_lora_state(unet), t["plain.final"]) < 1e-3
     finally:
         dist.destroy_process_group()
+
+
+def test_pack_factors_and_partial_reduce_entry_points(relerr):
+    """lora_pack_factors(_batched), lora_linear_bwd_params (row-block partials) and lora_reduce_partials."""
+    g = torch.Generator().manual_seed(21)
+    K, N, r, M = 96, 160, 5, 300
+    a = torch.randn(r, K, generator=g).to(DEV)
+    b = torch.randn(N, r, generator=g).to(DEV)
+    for dt in (torch.float16, torch.float32):
+        apack, bpack = nat.lora_pack_factors(a, b, dt)
+        assert apack.shape == (32 * K,) and bpack.shape == (32 * N,) and apack.dtype == dt
+        a16, at16 = apack[: 16 * K].view(16, K), apack[16 * K:].view(K, 16)
+        bt16, b16 = bpack[: 16 * N].view(16, N), bpack[16 * N:].view(N, 16)
+        assert torch.equal(a16[:r], a.to(dt)) and torch.equal(bt16[:r], b.t().to(dt))
+        assert torch.equal(at16, a16.t()) and torch.equal(b16, bt16.t())
+        assert float(a16[r:].abs().max()) == 0.0 and float(bt16[r:].abs().max()) == 0.0
+    # batched form over a slab laid out [up(B) | down(A)] like the trainer's
+    params = torch.cat([b.reshape(-1), a.reshape(-1)]).contiguous()
+    table = torch.tensor([[N * r, 0, K, N, r, 0, 32 * K, 0]], dtype=torch.int64, device=DEV)
+    packed = torch.empty(32 * (K + N), dtype=torch.float16, device=DEV)
+    nat.lora_pack_factors_batched(table, 1, max(K, N), params, packed)
+    ap, bp = nat.lora_pack_factors(a, b, torch.float16)
+    assert torch.equal(packed[: 32 * K], ap) and torch.equal(packed[32 * K:], bp)
+    # partial sums: any block count gives the same gradients after the ordered fold; folds are deterministic
+    x = torch.randn(M, K, generator=g).to(DEV).half()
+    dy = torch.randn(M, N, generator=g).to(DEV).half()
+    t = torch.randn(M, r, generator=g).to(DEV)
+    u = torch.randn(M, r, generator=g).to(DEV)
+    ref_gb = (dy.double().t() @ t.double()).cpu()
+    ref_ga = (u.double().t() @ x.double()).cpu()
+    size = r * (K + N)
+    stride = (size + 3) // 4 * 4
+    outs = []
+    for nb in (1, 3, 7, 64):
+        ws = torch.full((nb, stride), float("nan"), device=DEV)  # every block must be fully written
+        nat.lora_linear_bwd_params_partial(dy, x, t, u, ws[0], ws[0, r * K:], stride, nb, 1.0)
+        out = torch.ones(stride, device=DEV)
+        nat.lora_reduce_partials(ws, stride, nb, out, size, True)   # accumulate onto ones
+        ga, gb = out[: r * K].view(r, K) - 1, out[r * K: size].view(N, r) - 1
+        assert relerr(ga, ref_ga) < 1e-5 and relerr(gb, ref_gb) < 1e-5, nb
+        out2 = torch.empty(stride, device=DEV)
+        nat.lora_reduce_partials(ws, stride, nb, out2, size, False)
+        out3 = torch.empty(stride, device=DEV)
+        nat.lora_reduce_partials(ws, stride, nb, out3, size, False)
+        assert torch.equal(out2[:size], out3[:size])
+        outs.append(out2[:size].clone())
+    # empty batch: partials are written as zeros
+    ws = torch.full((2, stride), float("nan"), device=DEV)
+    nat.lora_linear_bwd_params_partial(dy[:0], x[:0], t[:0], u[:0], ws[0], ws[0, r * K:], stride, 2, 1.0)
+    assert float(ws[:, :size].abs().max()) == 0.0
+
+
+def test_hot_path_kernels_are_deterministic():
+    """No atomics anywhere on the path: repeated launches on the same inputs are bit-identical (the stock PyTorch
+    convolution/attention backward kernels around them are not, so this is asserted per kernel, not per step)."""
+    g = torch.Generator().manual_seed(8)
+    M, K, N, r = 4096, 640, 640, 4
+    x = torch.randn(M, K, generator=g).to(DEV).half()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV).half()
+    a, b = (torch.randn(r, K, generator=g) / r).to(DEV), (torch.randn(N, r, generator=g) * 0.05).to(DEV)
+    dy = torch.randn(M, N, generator=g).to(DEV).half()
+    wt = w.t().contiguous()
+    runs = []
+    for _ in range(3):
+        y, t = nat.lora_linear_fwd(x, w, None, a, b, 1.0)
+        dx, u = nat.lora_linear_bwd_input(dy, wt, a, b, 1.0, True)
+        ga, gb = torch.zeros(r, K, device=DEV), torch.zeros(N, r, device=DEV)
+        nat.lora_linear_bwd_params(dy, x, t, u, ga, gb, 1.0)
+        p = torch.randn(M * 16, generator=torch.Generator().manual_seed(1)).to(DEV)
+        norm = torch.zeros(4, device=DEV)
+        nat.lora_grad_sqnorm(p, 1.0, norm)
+        runs.append((y, t, dx, u, ga, gb, norm.clone()))
+    for other in runs[1:]:
+        for first, again in zip(runs[0], other):
+            assert torch.equal(first, again)

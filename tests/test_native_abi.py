@@ -34,9 +34,9 @@ def test_version_and_status_strings_without_gpu():
 def test_argument_validation_needs_no_gpu():
     lib = nat.lib()
     # null pointers / bad rank are rejected before any HIP call
-    assert lib.lora_linear_fwd(None, None, None, None, None, None, None, None, 4, 8, 8,2, 1.0, 1, None) == -1
-    assert lib.lora_linear_fwd(None, None, None, None, None, None, None, None, 4, 8, 8,9, 1.0, 1, None) == -2
-    assert lib.lora_linear_fwd(None, None, None, None, None, None, None, None, 4, 8, 8,2, 1.0, 7, None) == -1
+    assert lib.lora_linear_fwd(None, None, None, None, None, None, None, None, None, 4, 8, 8,2, 1.0, 1, None) == -1
+    assert lib.lora_linear_fwd(None, None, None, None, None, None, None, None, None, 4, 8, 8,9, 1.0, 1, None) == -2
+    assert lib.lora_linear_fwd(None, None, None, None, None, None, None, None, None, 4, 8, 8,2, 1.0, 7, None) == -1
     assert lib.lora_linear_bwd_params(None, None, None, None, None, None, 0, 1, 4, 8, 8, 0, 1.0, 1, None) == -2
     assert lib.lora_reduce_partials(None, 0, 1, None, 4, 0, None) == -1
 
