@@ -349,6 +349,7 @@ class LoraTrainer:
         self.slab.check_all_layers_ran()
         self.exchange.finish()
         self.opt.step(grad_mul=1.0 / (self.world * self.loss_scale))
+        self.slab.repack()  # forwards outside step() (sampling, evaluation, saving merged weights) see the new factors
         return loss
 
 

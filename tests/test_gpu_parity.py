@@ -505,3 +505,89 @@ def test_hot_path_kernels_are_deterministic():
     for other in runs[1:]:
         for first, again in zip(runs[0], other):
             assert torch.equal(first, again)
+
+
+def test_cfg3_text_encoder_lora_rank8(relerr):
+    """BASELINE config 3: LoRA rank 8 on the CLIP text encoder (target class CLIPAttention, lora.py:54).  The
+    transformers CLIP forward is the caller; only the four projections per layer run on the HIP path."""
+    from transformers import CLIPTextConfig, CLIPTextModel
+
+    cfg = CLIPTextConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+                         vocab_size=100, max_position_embeddings=16, bos_token_id=1, eos_token_id=2, pad_token_id=0)
+    torch.manual_seed(0)
+    ref = CLIPTextModel(cfg)
+    ref.requires_grad_(False)
+    gpu = CLIPTextModel(cfg)
+    gpu.load_state_dict(ref.state_dict())
+    gpu.requires_grad_(False)
+    gpu.to(DEV)
+    ref_params, ref_names = orc.inject(ref, orc.TEXT_ENCODER_TARGETS, r=8)
+    params, names = dfa.inject_trainable_lora(gpu, dfa.TEXT_ENCODER_DEFAULT_TARGET_REPLACE, r=8)
+    plist = list(itertools.chain(*params))
+    assert names == ref_names and len(plist) == len(ref_params) == 2 * 4 * 2
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for p_ref, p in zip(ref_params, plist):
+            p_ref.copy_(torch.randn(p_ref.shape, generator=g) * 0.05)
+            p.copy_(p_ref.to(DEV))
+    ids = torch.randint(3, 100, (3, 16), generator=g)
+    wgt = torch.randn(3, 16, 64, generator=g)
+    out_ref = ref(ids)[0]
+    (out_ref * wgt).sum().backward()
+    out = gpu(ids.to(DEV))[0]
+    (out * wgt.to(DEV)).sum().backward()
+    assert relerr(out, out_ref.detach()) < 1e-4
+    for p_ref, p in zip(ref_params, plist):
+        assert relerr(p.grad, p_ref.grad) < 1e-3
+
+
+def test_cfg5_sd21_shape_rank16_v_prediction(relerr):
+    """BASELINE config 5 in miniature: SD2.x-style UNet (linear proj_in/out), rank 16, v-prediction target."""
+    from diffusion_finetuning_amd.unet import UNet2DConditionModel, UNetConfig
+
+    cfg = UNetConfig(block_out_channels=(32, 64), down_attention=(True, False), layers_per_block=1, num_heads=(2, 2),
+                     cross_attention_dim=48, norm_groups=8, linear_projection=True, name="tiny-sd21")
+
+    def make():
+        torch.manual_seed(9)
+        m = UNet2DConditionModel(cfg)
+        m.requires_grad_(False)
+        return m
+
+    ref = make()
+    ref_params, _ = orc.inject(ref, r=16)
+    unet = make().to(DEV)
+    params, _ = dfa.inject_trainable_lora(unet, r=16)
+    plist = list(itertools.chain(*params))
+    g = torch.Generator().manual_seed(2)
+    with torch.no_grad():
+        for i, (p_ref, p) in enumerate(zip(ref_params, plist)):
+            if i % 2 == 0:
+                p_ref.copy_(torch.randn(p_ref.shape, generator=g) * 0.02)
+            p.copy_(p_ref.to(DEV))
+    ref_losses = orc.train_steps(ref, ref_params, 3, 2, 8, 5, 48, lr=1e-3, v_prediction=True)
+    trainer = tr.LoraTrainer(unet, lr=1e-3, v_prediction=True)
+    losses = []
+    for step in range(3):
+        latents, noise, ts, ctx = orc.synthetic_batch(step, 2, 8, 5, 48)
+        losses.append(trainer.step(latents.to(DEV), noise.to(DEV), ts.to(DEV), ctx.to(DEV)).item())
+    assert relerr(torch.tensor(losses), torch.tensor(ref_losses)) < 1e-4
+    assert relerr(tr.flat_lora_state(unet), orc.flat_params(ref_params)) < 1e-3
+
+
+def test_rank_above_16_uses_generic_kernels(relerr):
+    """Ranks the fused tiles do not cover (r > 16) stay on the HIP device (shape-agnostic kernels)."""
+    g = torch.Generator().manual_seed(5)
+    M, K, N, r = 70, 48, 40, 20
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / 7
+    a, b = torch.randn(r, K, generator=g) / r, torch.randn(N, r, generator=g) * 0.05
+    dy = torch.randn(M, N, generator=g)
+    y_ref = orc.lora_linear_forward(x, w, None, a, b, 0.9)
+    dx_ref, ga_ref, gb_ref = orc.lora_linear_backward(x, w, a, b, 0.9, dy)
+    y, t = nat.lora_linear_fwd(x.to(DEV), w.to(DEV), None, a.to(DEV), b.to(DEV), 0.9)
+    dx, u = nat.lora_linear_bwd_input(dy.to(DEV), w.t().contiguous().to(DEV), a.to(DEV), b.to(DEV), 0.9, True)
+    ga, gb = torch.zeros(r, K, device=DEV), torch.zeros(N, r, device=DEV)
+    nat.lora_linear_bwd_params(dy.to(DEV), x.to(DEV), t, u, ga, gb, 0.9)
+    for got, want in ((y, y_ref), (dx, dx_ref), (ga, ga_ref), (gb, gb_ref)):
+        assert relerr(got, want) < 2e-5
