@@ -86,10 +86,10 @@ def measured_traffic(kernel_name, dtype):
         return None
     table = json.load(open(files[-1]))
     if m:
-        key = f"lora_gemm_kernel<DF16_,{m.group(1)},{m.group(2)},{1 if m.group(3) == 'true' else 0},1>"
+        prefix = f"lora_gemm_kernel<DF16_,{m.group(1)},{m.group(2)},{1 if m.group(3) == 'true' else 0}"
     else:
-        key = next((k for k in table if kernel_name.split("<")[0] in k), None)
-    entry = table.get(key)
+        prefix = kernel_name.split("<")[0]
+    entry = next((v for k, v in table.items() if k.startswith(prefix)), None)
     return entry["traffic_bytes_per_launch"] if entry else None
 
 
