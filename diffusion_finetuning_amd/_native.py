@@ -49,6 +49,8 @@ SIGNATURES = {
     "lora_sqnorm_workspace_bytes": (_i64, []),
     "lora_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
     "ddpm_add_noise": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
+    "ddpm_noise_prologue": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, ctypes.c_uint64, ctypes.c_uint64,
+                                   _i32, _i32, _vp]),
     "lora_prof_enable": (_i32, [_i32]),
     "lora_prof_collect": (_i32, [ctypes.POINTER(ProfTotals)]),
     "lora_prof_kernel_name": (ctypes.c_char_p, [_i32]),
@@ -305,6 +307,23 @@ def ddpm_add_noise(x0, eps, t, sqrt_acp, sqrt_1macp, out_dtype: torch.dtype, v_p
                                 _ptr(target), B, per_row, int(v_prediction), dtype_code(out_dtype), _stream(x0)),
            "ddpm_add_noise")
     return noisy, target
+
+
+def ddpm_noise_prologue(x0, sqrt_acp, sqrt_1macp, out_dtype: torch.dtype, seed: int, step: int, v_prediction: bool,
+                        n_timesteps: int = 1000, want_draw: bool = False):
+    """Draws eps/t on the device (Philox keyed by seed, step) and returns (noisy, target, t[, eps])."""
+    _require_device(x0, sqrt_acp, sqrt_1macp)
+    B = x0.shape[0]
+    per_row = x0[0].numel()
+    noisy = torch.empty(x0.shape, dtype=out_dtype, device=x0.device)
+    target = torch.empty(x0.shape, dtype=out_dtype, device=x0.device)
+    t = torch.empty(B, dtype=torch.int64, device=x0.device)
+    eps = torch.empty(x0.shape, dtype=torch.float32, device=x0.device) if want_draw else None
+    _check(lib().ddpm_noise_prologue(_ptr(x0), _ptr(sqrt_acp), _ptr(sqrt_1macp), _ptr(noisy), _ptr(target), _ptr(eps),
+                                     _ptr(t), B, per_row, int(n_timesteps), int(seed) & (2**64 - 1),
+                                     int(step) & (2**64 - 1), int(v_prediction), dtype_code(out_dtype), _stream(x0)),
+           "ddpm_noise_prologue")
+    return (noisy, target, t, eps) if want_draw else (noisy, target, t)
 
 
 def prof_enable(capacity: int) -> None:

@@ -248,3 +248,103 @@ extern "C" int ddpm_add_noise(const float* x0, const float* eps, const int64_t* 
     LORA_LAUNCH_CHECK();
     return LORA_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Step prologue with build-owned, counter-based randomness:
+//   t_b  ~ U{0..T-1},  eps ~ N(0,1)  from Philox4x32-10 keyed by (seed, step) — the same stream on every rank
+//   (set_seed semantics of train_lora_dreambooth.py:509-510) and on the CPU oracle (oracle/philox.py) —
+//   then noisy = sqrt_acp[t]·x0 + sqrt_1macp[t]·eps and target = eps | velocity, in ONE elementwise launch that
+//   replaces randn_like + randint + add_noise (+ get_velocity) of train_lora_dreambooth.py:824-853.
+// Counter layout: element group g (4 consecutive elements) uses counter (g, 0, stream, 0) with stream 0 for
+// eps and 1 for the timesteps (row b uses counter (b, 0, 1, 0), first word).  Normals: Box–Muller on the two
+// word pairs, u = (x + 0.5)·2^-32 ∈ (0,1).
+namespace {
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)x + 0.5f) * 2.3283064365386963e-10f; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void noise_prologue_kernel(const float* x0, const float* sa, const float* sb,
+                                                             T* noisy, T* target, float* eps_out, int64_t* t_out,
+                                                             int B, int64_t per_row, int n_timesteps, uint32_t seed,
+                                                             uint32_t step, int v_pred) {
+    const int64_t n_total = (int64_t)B * per_row;
+    const int64_t groups = (n_total + 3) >> 2;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < groups; g += (int64_t)gridDim.x * 256) {
+        uint32_t r[4];
+        philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), 0u, 0u, seed, step, r);
+        float z[4];
+        {
+            const float r0 = sqrtf(-2.f * logf(u01(r[0]))), r1 = sqrtf(-2.f * logf(u01(r[2])));
+            float s0, c0, s1, c1;
+            sincosf(6.283185307179586f * u01(r[1]), &s0, &c0);
+            sincosf(6.283185307179586f * u01(r[3]), &s1, &c1);
+            z[0] = r0 * c0; z[1] = r0 * s0; z[2] = r1 * c1; z[3] = r1 * s1;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t i = g * 4 + e;
+            if (i >= n_total) break;
+            const int64_t b = i / per_row;
+            uint32_t tr[4];
+            philox4x32_10((uint32_t)b, 0u, 1u, 0u, seed, step, tr);
+            const int64_t ti = (int64_t)(((uint64_t)tr[0] * (uint64_t)n_timesteps) >> 32);
+            if (i == b * per_row && t_out) t_out[b] = ti;
+            const float a = sa[ti], s = sb[ti];
+            const float x = x0[i];
+            noisy[i] = from_f32<T>(a * x + s * z[e]);
+            if (target) target[i] = from_f32<T>(v_pred ? a * z[e] - s * x : z[e]);
+            if (eps_out) eps_out[i] = z[e];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ddpm_noise_prologue(const float* x0, const float* sqrt_acp, const float* sqrt_1macp, void* noisy,
+                                   void* target, float* eps_out, int64_t* t_out, int B, int64_t per_row,
+                                   int n_timesteps, uint64_t seed, uint64_t step, int v_prediction, int dtype,
+                                   void* stream) {
+    if (!x0 || !sqrt_acp || !sqrt_1macp || !noisy || B < 1 || per_row < 1 || n_timesteps < 1) return LORA_E_BADARG;
+    const int64_t groups = ((int64_t)B * per_row + 3) / 4;
+    int64_t blocks = (groups + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t sd = (uint32_t)seed, st = (uint32_t)step;
+    switch (dtype) {
+        case LORA_F32:
+            hipLaunchKernelGGL(noise_prologue_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, x0, sqrt_acp,
+                               sqrt_1macp, static_cast<float*>(noisy), static_cast<float*>(target), eps_out, t_out, B,
+                               per_row, n_timesteps, sd, st, v_prediction);
+            break;
+        case LORA_F16:
+            hipLaunchKernelGGL(noise_prologue_kernel<half_t>, dim3((unsigned)blocks), dim3(256), 0, s, x0, sqrt_acp,
+                               sqrt_1macp, static_cast<half_t*>(noisy), static_cast<half_t*>(target), eps_out, t_out, B,
+                               per_row, n_timesteps, sd, st, v_prediction);
+            break;
+        case LORA_BF16:
+            hipLaunchKernelGGL(noise_prologue_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, x0, sqrt_acp,
+                               sqrt_1macp, static_cast<bf16_t*>(noisy), static_cast<bf16_t*>(target), eps_out, t_out, B,
+                               per_row, n_timesteps, sd, st, v_prediction);
+            break;
+        default: return LORA_E_BADARG;
+    }
+    LORA_LAUNCH_CHECK();
+    return LORA_OK;
+}

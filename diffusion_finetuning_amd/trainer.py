@@ -329,12 +329,21 @@ class LoraTrainer:
 
     # -- one step ---------------------------------------------------------------------------------
     def step(self, latents, noise, timesteps, encoder_hidden_states, *, with_prior_preservation=False,
-             prior_loss_weight=1.0, mask=None):
-        """latents/noise fp32 [B,4,h,w] on the device, timesteps int64 [B], encoder_hidden_states [B,L,D]."""
+             prior_loss_weight=1.0, mask=None, seed: Optional[int] = None):
+        """latents fp32 [B,4,h,w] on the device, encoder_hidden_states [B,L,D].  Either pass `noise` (fp32, like
+        latents) and `timesteps` (int64 [B]) — the caller drew them, as the reference does — or pass None for both and
+        a `seed`: the step then draws them on the device (Philox keyed by (seed, optimizer step), identical on
+        every rank) inside the prologue kernel."""
         self.slab.zero_grad()
         self.slab.repack()  # packed compute-dtype factors follow the fp32 masters (also after external edits)
-        noisy, target = nat.ddpm_add_noise(latents, noise, timesteps, self.sqrt_acp, self.sqrt_1macp, self.dtype,
-                                           self.v_prediction)
+        if noise is None:
+            if seed is None:
+                raise ValueError("pass noise and timesteps, or a seed for the on-device draw")
+            noisy, target, timesteps = nat.ddpm_noise_prologue(latents, self.sqrt_acp, self.sqrt_1macp, self.dtype, seed,
+                                                               self.opt.step_count, self.v_prediction)
+        else:
+            noisy, target = nat.ddpm_add_noise(latents, noise, timesteps, self.sqrt_acp, self.sqrt_1macp, self.dtype,
+                                               self.v_prediction)
         self.exchange.arm()
         pred = self.unet(noisy, timesteps, encoder_hidden_states.to(self.dtype)).sample
         rows = pred.shape[0]

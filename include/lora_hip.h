@@ -180,6 +180,20 @@ int ddpm_add_noise(const float* x0, const float* eps, const int64_t* t, const fl
                    int v_prediction, int dtype, void* stream);
 
 /*
+ * Step prologue with build-owned, counter-based randomness: replaces randn_like + randint +
+ * add_noise (+ get_velocity) of training_scripts/train_lora_dreambooth.py:824-853 by one launch.
+ *     t_b ~ U{0..n_timesteps-1},  eps ~ N(0,1)   from Philox4x32-10 keyed by (seed, step): the same draw on every
+ *     rank (set_seed semantics, :509-510) and on the CPU oracle (oracle/philox.py);
+ *     noisy / target as in ddpm_add_noise.  eps_out (fp32) and t_out (int64) are optional copies of the draw.
+ * Counter layout: element group g = i/4 uses counter (g, 0, 0, 0) → 4 normals by Box–Muller; row b uses
+ * counter (b, 0, 1, 0), word 0, mapped to [0, n_timesteps) by the high half of a 32×32-bit product.
+ */
+int ddpm_noise_prologue(const float* x0, const float* sqrt_acp, const float* sqrt_1macp, void* noisy,
+                        void* target /* nullable */, float* eps_out /* nullable */, int64_t* t_out /* nullable */,
+                        int B, int64_t per_row, int n_timesteps, uint64_t seed, uint64_t step,
+                        int v_prediction, int dtype, void* stream);
+
+/*
  * Launch profiler (measurement only; off by default).  When enabled, the hot-path kernels are launched
  * with start/stop events attached to the dispatch itself, so each record is that kernel's own duration on
  * the caller's stream, together with the ALGORITHMIC bytes and flops of the call (formulas: DESIGN.md §5).

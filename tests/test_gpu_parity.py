@@ -591,3 +591,36 @@ def test_rank_above_16_uses_generic_kernels(relerr):
     nat.lora_linear_bwd_params(dy.to(DEV), x.to(DEV), t, u, ga, gb, 0.9)
     for got, want in ((y, y_ref), (dx, dx_ref), (ga, ga_ref), (gb, gb_ref)):
         assert relerr(got, want) < 2e-5
+
+
+def test_noise_prologue_matches_philox_oracle(relerr):
+    """f-3: on-device draw (Philox4x32-10 + Box–Muller) + add_noise/target in one launch vs the numpy oracle."""
+    import numpy as np
+
+    from oracle import philox
+
+    acp = orc.ddpm_alphas_cumprod()
+    sa, sb = tr.ddpm_tables(device=DEV)
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.randn(5, 4, 16, 16, generator=g) * 0.18215
+    for v in (False, True):
+        noisy, target, t, eps = nat.ddpm_noise_prologue(x0.to(DEV), sa, sb, torch.float32, 77, 3, v, want_draw=True)
+        eps_ref, t_ref = philox.step_randomness(5, 4 * 16 * 16, 1000, 77, 3)
+        assert np.array_equal(t.cpu().numpy(), t_ref)  # integer stream: bit-exact
+        eps_ref = torch.from_numpy(eps_ref).reshape(x0.shape)
+        assert float((eps.cpu() - eps_ref).abs().max()) < 2e-5  # libm vs GPU logf/sincosf
+        tt = torch.from_numpy(t_ref)
+        assert relerr(noisy, orc.add_noise(x0, eps_ref, tt, acp)) < 1e-5
+        assert relerr(target, orc.get_velocity(x0, eps_ref, tt, acp) if v else eps_ref) < 1e-5
+    # same (seed, step) → same draw; the trainer's seeded step runs end to end
+    a = nat.ddpm_noise_prologue(x0.to(DEV), sa, sb, torch.float16, 1, 2, False)
+    b = nat.ddpm_noise_prologue(x0.to(DEV), sa, sb, torch.float16, 1, 2, False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+    from tests.conftest import build_tiny_unet
+
+    unet = build_tiny_unet().to(DEV)
+    dfa.inject_trainable_lora(unet, r=4)
+    trainer = tr.LoraTrainer(unet, lr=1e-3)
+    lat, _, _, ctx = orc.synthetic_batch(0, 2, 8, 6, 32)
+    l0 = trainer.step(lat.to(DEV), None, None, ctx.to(DEV), seed=5)
+    assert torch.isfinite(l0).all()

@@ -129,3 +129,23 @@ def test_ddpm_schedule_properties():
     # (noisy, velocity) is a rotation of (x0, eps): invertible
     assert torch.allclose(a * noisy - s * vel, x0, atol=1e-5)
     assert torch.allclose(s * noisy + a * vel, eps, atol=1e-5)
+
+
+def test_philox_known_answers_and_statistics():
+    """Philox4x32-10 against the Random123 known-answer vectors; the derived normals/timesteps are sane."""
+    import numpy as np
+
+    from oracle import philox
+
+    def kat(c, k):
+        return [int(x[0]) for x in philox.philox4x32_10(*[np.array([v], dtype=np.uint32) for v in c], *k)]
+
+    assert kat((0, 0, 0, 0), (0, 0)) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert kat((0xFFFFFFFF,) * 4, (0xFFFFFFFF, 0xFFFFFFFF)) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert kat((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0)) == [0xD16CFE09, 0x94FDCCEB,
+                                                                                               0x5001E420, 0x24126EA1]
+    eps, t = philox.step_randomness(8, 4 * 64 * 64, 1000, 1234, 7)
+    assert abs(float(eps.mean())) < 0.01 and abs(float(eps.std()) - 1.0) < 0.01 and np.isfinite(eps).all()
+    assert t.min() >= 0 and t.max() < 1000
+    eps2, t2 = philox.step_randomness(8, 4 * 64 * 64, 1000, 1234, 8)
+    assert not np.array_equal(t, t2) and abs(float((eps * eps2).mean())) < 0.01  # steps are independent streams
