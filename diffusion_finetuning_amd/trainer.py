@@ -22,7 +22,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import _native as nat
-from .lora import LoraInjectedLinear
+from .core import LoraInjectedLinear
 
 
 def ddpm_tables(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, device="cpu"):
