@@ -10,7 +10,8 @@
 // orientations.  F arrives PACKED: [16, Kc] in the compute dtype, rows ≥ r zero
 // (lora_pack_factors), so it is staged exactly like an operand tile.
 //
-// Structure per 256-thread workgroup (4 waves as 2×2), BM×BN output tile, 128-byte K-steps:
+// Structure per workgroup of NW waves (2 row waves × NW/2 column waves; 256 or 512 threads), BM×BN output tile,
+// 128-byte K-steps:
 //   - PIPE main loop: a 3-stage LDS ring filled by LDS-DMA (global_load_lds, 16 B per lane, no VGPR
 //     staging), two K-steps in flight behind a COUNTED s_waitcnt vmcnt and one raw s_barrier per step.
 //     The XOR swizzle of the 16-B chunks is applied to the per-lane SOURCE address (the DMA writes LDS in
@@ -71,35 +72,41 @@ template <> struct Mfma<bf16_t> {
     }
 };
 
-// One stage of the ring / the single staging buffer: A rows, B rows, 32 factor rows (two identical
-// 16-row copies so that every wave issues the same number of DMA loads per stage).
-template <int BM, int BN, bool MAIN> constexpr int stage_bytes() {
-    return (BM + (MAIN ? BN : 0) + 2 * kRP) * kRowBytes;
+// One stage of the ring / the single staging buffer: A rows, B rows, factor rows.  With counted waits (3 stages) every
+// wave must issue the same number of DMA loads per stage, so the 16 factor rows are replicated over one staging pass;
+// with the 2-stage ring every wait is vmcnt(0) and only the first two waves load the factor tile.
+template <int BM, int BN, bool MAIN, int STG, int NW> constexpr int stage_bytes() {
+    return (BM + (MAIN ? BN : 0) + (STG == 2 ? kRP : NW * 8)) * kRowBytes;
 }
-template <int BM, int BN, typename T, bool MAIN, int STG> constexpr int gemm_lds_bytes() {
-    constexpr int ring = (STG > 0 ? STG : 1) * stage_bytes<BM, BN, MAIN>();
+template <int BM, int BN, typename T, bool MAIN, int STG, int NW> constexpr int gemm_lds_bytes() {
+    constexpr int ring = (STG > 0 ? STG : 1) * stage_bytes<BM, BN, MAIN, STG, NW>();
     constexpr int sq = MAIN ? BN * kRP * (int)sizeof(T) : 0;
     constexpr int ep = sizeof(T) == 4 ? 2 : 1;
     constexpr int sc = MAIN ? (BM / ep) * (BN * (int)sizeof(T) + 16) : 0;
-    constexpr int sp = 2 * BM * kRP * 4;
+    constexpr int sp = (NW / 2) * BM * kRP * 4;
     constexpr int a = ring + sq;
     constexpr int b = sc > sp ? sc : sp;
     return a > b ? a : b;
 }
 
 // STG: LDS ring depth of the DMA pipeline (2 or 3); 0 selects the register-staged fallback loop.
-template <typename T, int BM, int BN, bool MAIN, int STG>
-__global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
+template <typename T, int BM, int BN, bool MAIN, int STG, int NW>
+__global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
     constexpr bool PIPE = STG > 0;
     constexpr int kStages = PIPE ? STG : 1;
+    constexpr int NT = NW * 64;        // threads
+    constexpr int WN = NW / 2;         // column waves (row waves: 2)
+    constexpr int WTN = BN / WN;       // wave tile width
+    constexpr int RPP = NW * 8;        // tile rows covered by one staging pass
+    constexpr int FROWS = STG == 2 ? kRP : RPP;
     constexpr int VEC = ElemTraits<T>::kVec;
     constexpr int BK = kRowBytes / (int)sizeof(T);
     constexpr int MI = BM / 32;  // 16-row fragments per wave
-    constexpr int NI = BN / 32;
-    constexpr int PA = BM / 32;  // staging passes (32 rows per pass)
-    constexpr int PB = BN / 32;
+    constexpr int NI = WTN / 16;
+    constexpr int PA = BM / RPP;  // staging passes
+    constexpr int PB = BN / RPP;
     constexpr bool F32 = sizeof(T) == 4;
-    constexpr int STAGE = stage_bytes<BM, BN, MAIN>();
+    constexpr int STAGE = stage_bytes<BM, BN, MAIN, STG, NW>();
     constexpr int OFF_B = BM * kRowBytes;
     constexpr int OFF_F = (BM + (MAIN ? BN : 0)) * kRowBytes;
 
@@ -110,8 +117,8 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1;
-    const int wn = wave & 1;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
     const int l15 = lane & 15;
     const int lq = lane >> 4;
 
@@ -141,14 +148,14 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
     const T* b_ptr[MAIN ? PB : 1];
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-        int64_t m = m0 + ld_row + 32 * i;
+        int64_t m = m0 + ld_row + RPP * i;
         if (m > p.M - 1) m = p.M - 1;  // clamp: rows past M are loaded from a valid row, never stored
         a_ptr[i] = Ag + m * p.Kc;
     }
     if constexpr (MAIN) {
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-            int n = n0 + ld_row + 32 * i;
+            int n = n0 + ld_row + RPP * i;
             if (n > p.Nc - 1) n = p.Nc - 1;
             b_ptr[i] = Bg + (int64_t)n * p.Kc;
         }
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
     if constexpr (MAIN) {
         constexpr int CPRQ = kRP * (int)sizeof(T) / 16;  // chunks per packed row (2 for 16-bit, 4 for f32)
         const T* Qg = static_cast<const T*>(p.Qp);
-        for (int idx = tid; idx < BN * CPRQ; idx += 256) {
+        for (int idx = tid; idx < BN * CPRQ; idx += NT) {
             const int n = idx / CPRQ, ch = idx - n * CPRQ;
             const int nn = n0 + n < p.Nc ? n0 + n : p.Nc - 1;
             *reinterpret_cast<Chunk<T>*>(sQ + idx * 16) =
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
     for (int i = 0; i < MI; ++i) pacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- one K-step of MFMA work out of a staged buffer ------------------------------------
-    auto compute = [&](const char* st) {
+    auto compute = [&](const char* st, int kt) {
         const char* sA = st;
         const char* sB = st + OFF_B;
         const char* sF = st + OFF_F;
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
                     af[mi] = *reinterpret_cast<const Frag*>(sA + lds_off(wm * (BM / 2) + mi * 16 + l15, chunk));
-                if (ks == wn) {
+                if ((kt * 2 + ks) % WN == wn) {
                     const Frag ff = *reinterpret_cast<const Frag*>(sF + lds_off(l15, chunk));
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) pacc[mi] = Mfma<T>::run(af[mi], ff, pacc[mi]);
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
                     Frag bf[NI];
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
-                        bf[ni] = *reinterpret_cast<const Frag*>(sB + lds_off(wn * (BN / 2) + ni * 16 + l15, chunk));
+                        bf[ni] = *reinterpret_cast<const Frag*>(sB + lds_off(wn * WTN + ni * 16 + l15, chunk));
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
                     af[mi] = *reinterpret_cast<const f32x4*>(sA + lds_off(wm * (BM / 2) + mi * 16 + l15, chunk));
-                if (h == wn) {
+                if ((kt * 2 + h) % WN == wn) {
                     const f32x4 ff = *reinterpret_cast<const f32x4*>(sF + lds_off(l15, chunk));
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -228,7 +235,7 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
                     f32x4 bf[NI];
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
-                        bf[ni] = *reinterpret_cast<const f32x4*>(sB + lds_off(wn * (BN / 2) + ni * 16 + l15, chunk));
+                        bf[ni] = *reinterpret_cast<const f32x4*>(sB + lds_off(wn * WTN + ni * 16 + l15, chunk));
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -253,12 +260,12 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
             char* st = smem + buf * STAGE + wave_rows;
             const int k0 = kt * BK + src_off;
 #pragma unroll
-            for (int i = 0; i < PA; ++i) glds16(a_ptr[i] + k0, st + 32 * i * kRowBytes);
+            for (int i = 0; i < PA; ++i) glds16(a_ptr[i] + k0, st + RPP * i * kRowBytes);
             if constexpr (MAIN) {
 #pragma unroll
-                for (int i = 0; i < PB; ++i) glds16(b_ptr[i] + k0, st + OFF_B + 32 * i * kRowBytes);
+                for (int i = 0; i < PB; ++i) glds16(b_ptr[i] + k0, st + OFF_B + RPP * i * kRowBytes);
             }
-            glds16(f_ptr + k0, st + OFF_F);
+            if (FROWS == RPP || wave < 2) glds16(f_ptr + k0, st + OFF_F);
         };
         constexpr int DIST = kStages - 1;  // K-steps in flight ahead of the one being multiplied
         issue(0, 0);
@@ -273,7 +280,7 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
             }
             __builtin_amdgcn_s_barrier();  // every wave's part of stage kt is in; stage kt-1 is fully read
             if (kt + DIST < nk) issue(kt + DIST, buf >= 1 ? buf - 1 : kStages - 1);  // refill the buffer read last step
-            compute(smem + buf * STAGE);
+            compute(smem + buf * STAGE, kt);
             buf = buf + 1 == kStages ? 0 : buf + 1;
         }
     } else {
@@ -309,11 +316,11 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
             }
 #pragma unroll
             for (int i = 0; i < PA; ++i)
-                *reinterpret_cast<Chunk<T>*>(smem + lds_off(ld_row + 32 * i, ld_chunk)) = ra[i];
+                *reinterpret_cast<Chunk<T>*>(smem + lds_off(ld_row + RPP * i, ld_chunk)) = ra[i];
             if constexpr (MAIN) {
 #pragma unroll
                 for (int i = 0; i < PB; ++i)
-                    *reinterpret_cast<Chunk<T>*>(smem + OFF_B + lds_off(ld_row + 32 * i, ld_chunk)) = rb[i];
+                    *reinterpret_cast<Chunk<T>*>(smem + OFF_B + lds_off(ld_row + RPP * i, ld_chunk)) = rb[i];
             }
             *reinterpret_cast<Chunk<T>*>(smem + OFF_F + lds_off(ld_row, ld_chunk)) = rfc;
         };
@@ -323,7 +330,7 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
             store_step();
             __syncthreads();
             if (kt + 1 < nk) load_step((kt + 1) * BK);
-            compute(smem);
+            compute(smem, kt);
         }
     }
 
@@ -344,7 +351,12 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int j = half * 8 + e;
-                if (j < p.r) p.P[(m0 + row) * p.r + j] = sP[row * kRP + j] + sP[(BM + row) * kRP + j];
+                if (j < p.r) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WN; ++w) v += sP[(w * BM + row) * kRP + j];
+                    p.P[(m0 + row) * p.r + j] = v;
+                }
             }
         }
     }
@@ -358,14 +370,17 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
                 qf[ni] = *reinterpret_cast<const Frag*>(
-                    sQ + ((wn * (BN / 2) + ni * 16 + l15) * kRP + j0) * (int)sizeof(T));
+                    sQ + ((wn * WTN + ni * 16 + l15) * kRP + j0) * (int)sizeof(T));
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 const int row = wm * (BM / 2) + mi * 16 + l15;
                 Frag pf;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float v = (sP[row * kRP + j0 + e] + sP[(BM + row) * kRP + j0 + e]) * p.scale;
+                    float v = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WN; ++w) v += sP[(w * BM + row) * kRP + j0 + e];
+                    v *= p.scale;
                     const T hi = from_f32<T>(v);
                     const T lo = from_f32<T>(v - to_f32<T>(hi));
                     pf[e] = lq < 2 ? hi : lo;
@@ -380,11 +395,14 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
                 const int j = 4 * st + lq;
                 float qv[NI];
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) qv[ni] = q[(wn * (BN / 2) + ni * 16 + l15) * kRP + j];
+                for (int ni = 0; ni < NI; ++ni) qv[ni] = q[(wn * WTN + ni * 16 + l15) * kRP + j];
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
                     const int row = wm * (BM / 2) + mi * 16 + l15;
-                    const float pv = (sP[row * kRP + j] + sP[(BM + row) * kRP + j]) * p.scale;
+                    float pv = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WN; ++w) pv += sP[(w * BM + row) * kRP + j];
+                    pv *= p.scale;
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, qv[ni], acc[mi][ni], 0, 0, 0);
@@ -397,7 +415,7 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
             const T* bias = static_cast<const T*>(p.bias);
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-                int col = n0 + wn * (BN / 2) + ni * 16 + l15;
+                int col = n0 + wn * WTN + ni * 16 + l15;
                 if (col > p.Nc - 1) col = p.Nc - 1;
                 const float bv = to_f32<T>(bias[col]);
 #pragma unroll
@@ -422,13 +440,13 @@ __global__ __launch_bounds__(256) void lora_gemm_kernel(GemmParams p) {
 #pragma unroll
                         for (int reg = 0; reg < 4; ++reg) {
                             const int row = (EP == 1 ? wm * (BM / 2) : 0) + mi * 16 + lq * 4 + reg;
-                            const int col = wn * (BN / 2) + ni * 16 + l15;
+                            const int col = wn * WTN + ni * 16 + l15;
                             *reinterpret_cast<T*>(smem + row * SC_STRIDE + col * (int)sizeof(T)) =
                                 from_f32<T>(acc[mi][ni][reg]);
                         }
             }
             __syncthreads();
-            for (int idx = tid; idx < ROWS * CPR; idx += 256) {
+            for (int idx = tid; idx < ROWS * CPR; idx += NT) {
                 const int row = idx / CPR, ch = idx - row * CPR;
                 const int64_t m = m0 + ep * ROWS + row;
                 const int col = n0 + ch * VEC;
@@ -520,12 +538,12 @@ __global__ __launch_bounds__(256) void pack_factors_batched_kernel(const int64_t
                 blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
-template <typename T, int BM, int BN, bool MAIN, int STG>
+template <typename T, int BM, int BN, bool MAIN, int STG, int NW = 4>
 int launch_tile(GemmParams p, hipStream_t stream) {
     p.tiles_m = (int)((p.M + BM - 1) / BM);
     p.tiles_n = MAIN ? (p.Nc + BN - 1) / BN : 1;
-    constexpr int lds = gemm_lds_bytes<BM, BN, T, MAIN, STG>();
-    auto kern = lora_gemm_kernel<T, BM, BN, MAIN, STG>;
+    constexpr int lds = gemm_lds_bytes<BM, BN, T, MAIN, STG, NW>();
+    auto kern = lora_gemm_kernel<T, BM, BN, MAIN, STG, NW>;
     if (lds > 48 * 1024) {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -533,7 +551,7 @@ int launch_tile(GemmParams p, hipStream_t stream) {
     }
     constexpr int prof_id = MAIN ? (BM == 128 && BN == 128 ? PK_GEMM_128x128 : (BM == 128 ? PK_GEMM_128x64 : PK_GEMM_64x64))
                                  : (BM == 128 ? PK_SKINNY_128 : PK_SKINNY_64);
-    LORA_LAUNCH(prof_id, kern, dim3(p.tiles_m * p.tiles_n), dim3(256), lds, stream, p);
+    LORA_LAUNCH(prof_id, kern, dim3(p.tiles_m * p.tiles_n), dim3(NW * 64), lds, stream, p);
     LORA_LAUNCH_CHECK();
     return LORA_OK;
 }
@@ -563,7 +581,11 @@ int launch_pipe(const GemmParams& p, hipStream_t stream) {
     static const int stg_env = [] { const char* e = getenv("LORA_FORCE_STAGES"); return e ? atoi(e) : 0; }();
     if (forced_tile() == 0) big = true;
     if (forced_tile() == 2) big = false;
-    if (big) return stg_env == 3 ? launch_tile<T, 128, 128, true, 3>(p, stream) : launch_tile<T, 128, 128, true, 2>(p, stream);
+    static const int nw_env = [] { const char* e = getenv("LORA_FORCE_WAVES"); return e ? atoi(e) : 0; }();
+    if (big) {
+        if (stg_env == 3) return launch_tile<T, 128, 128, true, 3>(p, stream);
+        return nw_env == 8 ? launch_tile<T, 128, 128, true, 2, 8>(p, stream) : launch_tile<T, 128, 128, true, 2, 4>(p, stream);
+    }
     if (stg_env == 2) deep = false;
     if (stg_env == 3) deep = true;
     return deep ? launch_tile<T, 64, 64, true, 3>(p, stream) : launch_tile<T, 64, 64, true, 2>(p, stream);

@@ -624,3 +624,60 @@ def test_noise_prologue_matches_philox_oracle(relerr):
     lat, _, _, ctx = orc.synthetic_batch(0, 2, 8, 6, 32)
     l0 = trainer.step(lat.to(DEV), None, None, ctx.to(DEV), seed=5)
     assert torch.isfinite(l0).all()
+
+
+def test_cfg3_unet_plus_text_encoder_training_step(relerr, tiny_unet_factory):
+    """BASELINE config 3 end to end (--train_text_encoder, train_lora_dreambooth.py:608-621,659-676): UNet LoRA r=4 and
+    CLIP LoRA r=8 in ONE slab with two learning rates; attn2 to_k/to_v now need dX (the text encoder trains)."""
+    from transformers import CLIPTextConfig, CLIPTextModel
+
+    ccfg = CLIPTextConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2,
+                          vocab_size=50, max_position_embeddings=8, bos_token_id=1, eos_token_id=2, pad_token_id=0)
+
+    def make():
+        torch.manual_seed(4)
+        te = CLIPTextModel(ccfg)
+        te.requires_grad_(False)
+        return tiny_unet_factory(seed=6), te
+
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(3, 50, (2, 8), generator=g)
+    lr_u, lr_t = 1e-3, 3e-4
+    # reference loop on the CPU (oracle pieces, two param groups)
+    ref_unet, ref_te = make()
+    pu, _ = orc.inject(ref_unet, r=4)
+    pt, _ = orc.inject(ref_te, orc.TEXT_ENCODER_TARGETS, r=8)
+    unet, te = make()
+    unet.to(DEV), te.to(DEV)
+    gu, _ = dfa.inject_trainable_lora(unet, r=4)
+    gt, _ = dfa.inject_trainable_lora(te, dfa.TEXT_ENCODER_DEFAULT_TARGET_REPLACE, r=8)
+    plist = list(itertools.chain(*gu)) + list(itertools.chain(*gt))
+    with torch.no_grad():
+        for i, (p_ref, p) in enumerate(zip(pu + pt, plist)):
+            if i % 2 == 0:
+                p_ref.copy_(torch.randn(p_ref.shape, generator=g) * 0.02)
+            p.copy_(p_ref.to(DEV))
+    acp = orc.ddpm_alphas_cumprod()
+    params = pu + pt
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+    trainer = tr.LoraTrainer(unet, te, lr=lr_u, lr_text=lr_t)
+    assert trainer.slab.model_ranges[1][0] == trainer.slab.model_ranges[0][1] > 0
+    for step in range(3):
+        latents, noise, ts, _ = orc.synthetic_batch(step, 2, 8, 6, 32)
+        for p in params:
+            p.grad = None
+        ehs = ref_te(ids)[0]
+        pred = ref_unet(orc.add_noise(latents, noise, ts, acp), ts, ehs).sample
+        orc.mse_loss(pred, noise).backward()
+        grads = [p.grad for p in params]
+        orc.clip_grad_norm(grads, 1.0)
+        with torch.no_grad():
+            for i, (p, gr, mm, vv) in enumerate(zip(params, grads, m, v)):
+                orc.adamw_step(p, gr, mm, vv, step + 1, lr_u if i < len(pu) else lr_t)
+        ehs_g = te(ids.to(DEV))[0]
+        trainer.step(latents.to(DEV), noise.to(DEV), ts.to(DEV), ehs_g)
+    n_u = sum(p.numel() for p in pu)
+    got = trainer.slab.params[: trainer.slab.numel].cpu()
+    want = orc.flat_params(params)
+    assert relerr(got[:n_u], want[:n_u]) < 1e-3 and relerr(got[n_u:], want[n_u:]) < 1e-3
