@@ -44,6 +44,7 @@ struct GemmParams {
     int Kc, Nc, r;
     float scale;
     int tiles_m, tiles_n;
+    int col_major;  // 1: consecutive tiles walk down M inside a column tile (an XCD then owns a slice of Bm)
 };
 
 constexpr int kRowBytes = 128;  // one K-step of one tile row
@@ -132,8 +133,11 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
         const int xcd = id & 7, slot = id >> 3;
         tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
     }
-    const int tm = tile / p.tiles_n;
-    const int tn = tile - tm * p.tiles_n;
+    // Which operand should stay inside one XCD's L2?  Row-major tile order keeps a row panel of Am there and makes
+    // every XCD stream all of Bm; column-major order keeps a slice of Bm there and streams Am instead.  The host
+    // picks the order that re-fetches the SMALLER operand eight times (col_major when Bm is the bigger one).
+    const int tm = p.col_major ? tile % p.tiles_m : tile / p.tiles_n;
+    const int tn = p.col_major ? tile / p.tiles_m : tile - tm * p.tiles_n;
     const int64_t m0 = (int64_t)tm * BM;
     const int n0 = tn * BN;
 
@@ -542,6 +546,8 @@ template <typename T, int BM, int BN, bool MAIN, int STG, int NW = 4>
 int launch_tile(GemmParams p, hipStream_t stream) {
     p.tiles_m = (int)((p.M + BM - 1) / BM);
     p.tiles_n = MAIN ? (p.Nc + BN - 1) / BN : 1;
+    static const int order_env = [] { const char* e = getenv("LORA_FORCE_COLMAJOR"); return e ? atoi(e) : -1; }();
+    p.col_major = order_env >= 0 ? order_env : (MAIN && (int64_t)p.Nc > p.M ? 1 : 0);
     constexpr int lds = gemm_lds_bytes<BM, BN, T, MAIN, STG, NW>();
     auto kern = lora_gemm_kernel<T, BM, BN, MAIN, STG, NW>;
     if (lds > 48 * 1024) {
