@@ -42,7 +42,7 @@ def parse():
 
 def build_model(device, dtype, rank_r):
     import diffusion_finetuning_amd as dfa
-    from diffusion_finetuning_amd.unet import UNet2DConditionModel, sd15_config
+    from harness.unet import UNet2DConditionModel, sd15_config
 
     torch.manual_seed(0)  # identical random-init weights on every rank (no checkpoints offline)
     with torch.device(device):
@@ -113,7 +113,7 @@ def log(msg):
 def cpu_baseline(latent, rank_r, steps):
     """The CPU oracle (a restatement of the reference path, kind="port") timed on this box's host cores on a
     bounded sample of the same workload: batch 1 at the same resolution, fp32 (the reference's CPU path)."""
-    from diffusion_finetuning_amd.unet import UNet2DConditionModel, sd15_config
+    from harness.unet import UNet2DConditionModel, sd15_config
     from oracle import lora_oracle as orc
 
     cores = usable_cpus()

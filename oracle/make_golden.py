@@ -130,7 +130,7 @@ def gen_losses():
 
 
 def build_tiny_unet(seed=0):
-    from diffusion_finetuning_amd.unet import UNet2DConditionModel, tiny_config
+    from harness.unet import UNet2DConditionModel, tiny_config
 
     torch.manual_seed(seed)
     unet = UNet2DConditionModel(tiny_config(32, 32, 2))
@@ -139,7 +139,7 @@ def build_tiny_unet(seed=0):
 
 
 def gen_finder_and_formats(ref, tmpdir):
-    from diffusion_finetuning_amd.unet import UNet2DConditionModel, sd15_config
+    from harness.unet import UNet2DConditionModel, sd15_config
 
     out = {}
     # (1) the shipped example pins the 144-entry SD1.5 index → (K, N) table and the key/metadata format

@@ -59,7 +59,7 @@ def relerr():
 
 
 def build_tiny_unet(seed=0):
-    from diffusion_finetuning_amd.unet import UNet2DConditionModel, tiny_config
+    from harness.unet import UNet2DConditionModel, tiny_config
 
     torch.manual_seed(seed)
     unet = UNet2DConditionModel(tiny_config(32, 32, 2))

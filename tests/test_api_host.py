@@ -11,7 +11,7 @@ import torch.nn as nn
 from safetensors import safe_open as st_open
 
 import diffusion_finetuning_amd as dfa
-from diffusion_finetuning_amd.unet import UNet2DConditionModel, sd15_config, sd21_768_config
+from harness.unet import UNet2DConditionModel, sd15_config, sd21_768_config
 
 
 def _names(model):

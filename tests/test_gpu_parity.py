@@ -543,7 +543,7 @@ def test_cfg3_text_encoder_lora_rank8(relerr):
 
 def test_cfg5_sd21_shape_rank16_v_prediction(relerr):
     """BASELINE config 5 in miniature: SD2.x-style UNet (linear proj_in/out), rank 16, v-prediction target."""
-    from diffusion_finetuning_amd.unet import UNet2DConditionModel, UNetConfig
+    from harness.unet import UNet2DConditionModel, UNetConfig
 
     cfg = UNetConfig(block_out_channels=(32, 64), down_attention=(True, False), layers_per_block=1, num_heads=(2, 2),
                      cross_attention_dim=48, norm_groups=8, linear_projection=True, name="tiny-sd21")
