@@ -51,6 +51,10 @@ SIGNATURES = {
     "ddpm_add_noise": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
     "ddpm_noise_prologue": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, ctypes.c_uint64, ctypes.c_uint64,
                                    _i32, _i32, _vp]),
+    "geglu_gate_fwd": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    "geglu_gate_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "attn_split_heads": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "attn_merge_heads": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "lora_prof_enable": (_i32, [_i32]),
     "lora_prof_collect": (_i32, [ctypes.POINTER(ProfTotals)]),
     "lora_prof_kernel_name": (ctypes.c_char_p, [_i32]),
@@ -324,6 +328,45 @@ def ddpm_noise_prologue(x0, sqrt_acp, sqrt_1macp, out_dtype: torch.dtype, seed: 
                                      int(step) & (2**64 - 1), int(v_prediction), dtype_code(out_dtype), _stream(x0)),
            "ddpm_noise_prologue")
     return (noisy, target, t, eps) if want_draw else (noisy, target, t)
+
+
+def geglu_gate_fwd(y2):
+    """y2 [M, 2C] contiguous → h·gelu(g) [M, C]."""
+    _require_device(y2)
+    M, C2 = y2.shape
+    out = torch.empty((M, C2 // 2), dtype=y2.dtype, device=y2.device)
+    _check(lib().geglu_gate_fwd(_ptr(y2), _ptr(out), M, C2 // 2, dtype_code(y2.dtype), _stream(y2)), "geglu_gate_fwd")
+    return out
+
+
+def geglu_gate_bwd(y2, dout2):
+    _require_device(y2, dout2)
+    M, C2 = y2.shape
+    dy = torch.empty_like(y2)
+    _check(lib().geglu_gate_bwd(_ptr(y2), _ptr(dout2), _ptr(dy), M, C2 // 2, dtype_code(y2.dtype), _stream(y2)),
+           "geglu_gate_bwd")
+    return dy
+
+
+def attn_split_heads(x3, heads: int, D: int):
+    """x3 [B, N, H·d] contiguous → [B, H, N, D] (zero-padded columns)."""
+    _require_device(x3)
+    B, N, HD = x3.shape
+    d = HD // heads
+    out = torch.empty((B, heads, N, D), dtype=x3.dtype, device=x3.device)
+    _check(lib().attn_split_heads(_ptr(x3), _ptr(out), B, N, heads, d, D, dtype_code(x3.dtype), _stream(x3)),
+           "attn_split_heads")
+    return out
+
+
+def attn_merge_heads(x4, d: int):
+    """x4 [B, H, N, D] contiguous → [B, N, H·d]."""
+    _require_device(x4)
+    B, H, N, D = x4.shape
+    out = torch.empty((B, N, H * d), dtype=x4.dtype, device=x4.device)
+    _check(lib().attn_merge_heads(_ptr(x4), _ptr(out), B, N, H, d, D, dtype_code(x4.dtype), _stream(x4)),
+           "attn_merge_heads")
+    return out
 
 
 def prof_enable(capacity: int) -> None:

@@ -111,28 +111,31 @@ class CrossAttention(nn.Module):
 
     def forward(self, x, context=None):
         context = x if context is None else context
-        b, n, _ = x.shape
         q, k, v = self.to_q(x), self.to_k(context), self.to_v(context)
-        split = lambda t: t.view(b, t.shape[1], self.heads, -1).transpose(1, 2)
-        o = _sdpa(split(q), split(k), split(v))
-        o = o.transpose(1, 2).reshape(b, n, -1)
-        return self.to_out[1](self.to_out[0](o))
+        return self.to_out[1](self.to_out[0](_attention_core(q, k, v, self.heads)))
 
 
-def _sdpa(q, k, v):
-    """softmax(QKᵀ/√d)V with the stock PyTorch kernels.  On the GPU the SD head sizes 40 and 80 are zero-padded to
-    64 and 128 first: the ROCm SDPA kernels are tuned for those sizes (measured on MI355X at 4096 tokens, d = 40,
-    forward+backward: 2.73 ms as is, 0.92 ms padded with the memory-efficient backend).  Zero columns add nothing to
-    QKᵀ and produce zero output columns, which are dropped again; the scale stays 1/√d of the true head size."""
-    d = q.shape[-1]
+def _attention_core(q, k, v, heads):
+    """softmax(QKᵀ/√d)V per head on [B, N, H·d] tensors, stock PyTorch SDPA kernels.
+
+    On the GPU the SD head sizes 40 and 80 are zero-padded to 64 and 128: the ROCm SDPA kernels are tuned for
+    those sizes (MI355X, 4096 tokens, d = 40, forward+backward: 2.73 ms as is, 0.92 ms padded with the
+    memory-efficient backend).  Zero columns add nothing to QKᵀ and produce zero output columns, which are dropped
+    again; the scale stays 1/√d of the true head size.  The [B,N,H·d] ↔ [B,H,N,D] re-layouts (with the padding)
+    are single streaming kernels (diffusion_finetuning_amd.sandwich) instead of generic strided copies."""
+    b, n, hd = q.shape
+    d = hd // heads
     if not q.is_cuda:
-        return F.scaled_dot_product_attention(q, k, v)
-    target = 64 if d < 64 else (128 if d < 128 else d)
-    if target != d:
-        q, k, v = (F.pad(t, (0, target - d)) for t in (q, k, v))
+        split = lambda t: t.view(b, t.shape[1], heads, d).transpose(1, 2)
+        o = F.scaled_dot_product_attention(split(q), split(k), split(v))
+        return o.transpose(1, 2).reshape(b, n, hd)
+    from diffusion_finetuning_amd.sandwich import merge_heads, split_heads
+
+    D = 64 if d < 64 else (128 if d < 128 else d)
+    q4, k4, v4 = split_heads(q, heads, D), split_heads(k, heads, D), split_heads(v, heads, D)
     with sdpa_kernel([SDPBackend.EFFICIENT_ATTENTION, SDPBackend.FLASH_ATTENTION, SDPBackend.MATH]):
-        o = F.scaled_dot_product_attention(q, k, v, scale=d ** -0.5)
-    return o[..., :d] if target != d else o
+        o = F.scaled_dot_product_attention(q4, k4, v4, scale=d ** -0.5)
+    return merge_heads(o, d)
 
 
 class GEGLU(nn.Module):
@@ -141,7 +144,12 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, x):
-        h, gate = self.proj(x).chunk(2, dim=-1)
+        y = self.proj(x)
+        if y.is_cuda:  # one fused pass forward, one backward (diffusion_finetuning_amd.sandwich)
+            from diffusion_finetuning_amd.sandwich import geglu_gate
+
+            return geglu_gate(y)
+        h, gate = y.chunk(2, dim=-1)
         return h * F.gelu(gate)
 
 

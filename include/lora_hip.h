@@ -194,6 +194,21 @@ int ddpm_noise_prologue(const float* x0, const float* sqrt_acp, const float* sqr
                         int v_prediction, int dtype, void* stream);
 
 /*
+ * The two ops sandwiched by the hot path inside a transformer block, as streaming kernels.
+ *   geglu_gate_fwd : out[M,C]  = h · gelu(g)  with [h | g] = y[M,2C], exact (erf) gelu — the body of diffusers'
+ *                    GEGLU.forward, the caller of the `proj` LoraInjectedLinear (target class "GEGLU", lora.py:53).
+ *   geglu_gate_bwd : dy[M,2C] = [dout·gelu(g) | dout·h·gelu'(g)], contiguous, consumed directly as dY by
+ *                    lora_linear_bwd_input / lora_linear_bwd_params of `proj`.
+ *   attn_split_heads : [B,N,H·d] → [B,H,N,D], D >= d, columns d..D-1 zero-filled (q/k/v into the attention core).
+ *   attn_merge_heads : [B,H,N,D] → [B,N,H·d] (the core's output back, padding dropped).  Each is the other's
+ *                    backward.  d and D multiples of 16 bytes.
+ */
+int geglu_gate_fwd(const void* y, void* out, int64_t M, int C, int dtype, void* stream);
+int geglu_gate_bwd(const void* y, const void* dout, void* dy, int64_t M, int C, int dtype, void* stream);
+int attn_split_heads(const void* src, void* dst, int B, int N, int H, int d, int D, int dtype, void* stream);
+int attn_merge_heads(const void* src, void* dst, int B, int N, int H, int d, int D, int dtype, void* stream);
+
+/*
  * Launch profiler (measurement only; off by default).  When enabled, the hot-path kernels are launched
  * with start/stop events attached to the dispatch itself, so each record is that kernel's own duration on
  * the caller's stream, together with the ALGORITHMIC bytes and flops of the call (formulas: DESIGN.md §5).

@@ -681,3 +681,38 @@ def test_cfg3_unet_plus_text_encoder_training_step(relerr, tiny_unet_factory):
     got = trainer.slab.params[: trainer.slab.numel].cpu()
     want = orc.flat_params(params)
     assert relerr(got[:n_u], want[:n_u]) < 1e-3 and relerr(got[n_u:], want[n_u:]) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_sandwich_ops_geglu_and_head_layouts(relerr, dtype):
+    """f-4 (first part): GEGLU gate and head split/merge kernels vs the stock PyTorch composites they replace."""
+    from diffusion_finetuning_amd.sandwich import geglu_gate, merge_heads, split_heads
+
+    g = torch.Generator().manual_seed(12)
+    y = torch.randn(3, 50, 2 * 64, generator=g)
+    dout = torch.randn(3, 50, 64, generator=g)
+    yr = y.double().requires_grad_(True)
+    h, gate = yr.chunk(2, dim=-1)
+    (h * torch.nn.functional.gelu(gate)).backward(dout.double())
+    yg = y.to(DEV).to(dtype).requires_grad_(True)
+    out = geglu_gate(yg)
+    out.backward(dout.to(DEV).to(dtype))
+    tol = 1e-6 if dtype == torch.float32 else 2e-3
+    hh, gg = y.to(dtype).double().chunk(2, dim=-1)
+    assert relerr(out, hh * torch.nn.functional.gelu(gg)) < tol
+    yq = y.to(dtype).double().requires_grad_(True)
+    h2, g2 = yq.chunk(2, dim=-1)
+    (h2 * torch.nn.functional.gelu(g2)).backward(dout.to(dtype).double())
+    assert relerr(yg.grad, yq.grad) < tol
+    # heads: split pads with zeros, merge drops the padding; each is the other's adjoint
+    B, N, H, d, D = 2, 37, 8, 40, 64
+    x = torch.randn(B, N, H * d, generator=g).to(dtype)
+    xs = x.to(DEV).requires_grad_(True)
+    s4 = split_heads(xs, H, D)
+    ref4 = torch.nn.functional.pad(x.view(B, N, H, d).transpose(1, 2), (0, D - d))
+    assert torch.equal(s4.cpu(), ref4)
+    back = merge_heads(s4, d)
+    assert torch.equal(back.cpu(), x)
+    w = torch.randn(B, H, N, D, generator=g).to(dtype)
+    s4.backward(w.to(DEV))
+    assert torch.equal(xs.grad.cpu(), w[..., :d].transpose(1, 2).reshape(B, N, H * d))
