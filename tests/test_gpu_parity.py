@@ -716,3 +716,53 @@ def test_sandwich_ops_geglu_and_head_layouts(relerr, dtype):
     w = torch.randn(B, H, N, D, generator=g).to(dtype)
     s4.backward(w.to(DEV))
     assert torch.equal(xs.grad.cpu(), w[..., :d].transpose(1, 2).reshape(B, N, H * d))
+
+
+def test_drop_in_under_ddp_autocast_and_checkpointing(golden_trajectory, tiny_unet_factory, relerr):
+    """What `accelerate` does around the reference trainer (train_lora_dreambooth.py:489-494,627-630,744-757): the
+    model wrapped in torch DistributedDataParallel (1-rank RCCL group), fp16 autocast with a GradScaler, and
+    gradient checkpointing (the fused forward is re-entered from the autograd thread).  The LoRA gradients must reach
+    the DDP reducer through ordinary autograd and the run must track the fp32 reference trajectory."""
+    import os
+
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from torch.utils.checkpoint import checkpoint
+
+    t, meta = golden_trajectory
+    cfg = json.loads(meta["plain"])
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        unet = tiny_unet_factory(seed=cfg["unet_seed"]).to(DEV)
+        params, _ = dfa.inject_trainable_lora(unet, r=4)
+        plist = list(itertools.chain(*params))
+        _warm(plist, cfg["warm_seed"], cfg["warm_std"])
+        # gradient checkpointing on every transformer block, as diffusers' enable_gradient_checkpointing does
+        for m in unet.modules():
+            if type(m).__name__ == "BasicTransformerBlock":
+                inner = m.forward
+                m.forward = (lambda f: lambda x, ctx: checkpoint(f, x, ctx, use_reentrant=False))(inner)
+        ddp = DDP(unet, device_ids=[0])
+        opt = torch.optim.AdamW(plist, lr=cfg["lr"], betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+        scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+        acp = orc.ddpm_alphas_cumprod()
+        for step in range(cfg["steps"]):
+            latents, noise, ts, ctx = orc.synthetic_batch(step, cfg["batch"], cfg["latent_hw"], cfg["ctx_len"], cfg["ctx_dim"])
+            noisy = orc.add_noise(latents, noise, ts, acp).to(DEV)
+            with torch.autocast("cuda", dtype=torch.float16):
+                pred = ddp(noisy, ts.to(DEV), ctx.to(DEV)).sample
+            loss = dfa.ddpm_mse_loss(pred, noise.to(DEV))
+            scaler.scale(loss).backward()
+            scaler.unscale_(opt)
+            torch.nn.utils.clip_grad_norm_(ddp.parameters(), 1.0)
+            scaler.step(opt)
+            scaler.update()
+            opt.zero_grad()
+        assert all(p.dtype == torch.float32 for p in plist)  # masters stay fp32 under autocast
+        upd = tr.flat_lora_state(unet).cpu() - t["plain.init"]
+        assert relerr(upd, t["plain.final"] - t["plain.init"]) < 0.1  # fp16 autocast vs the fp32 reference
+        assert relerr(tr.flat_lora_state(unet), t["plain.final"]) < 5e-3
+    finally:
+        dist.destroy_process_group()
