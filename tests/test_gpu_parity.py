@@ -766,3 +766,55 @@ def test_drop_in_under_ddp_autocast_and_checkpointing(golden_trajectory, tiny_un
         assert relerr(tr.flat_lora_state(unet), t["plain.final"]) < 5e-3
     finally:
         dist.destroy_process_group()
+
+
+def test_cfg1_full_size_sd15_fp32_trajectory_vs_cpu_oracle(relerr):
+    """BASELINE config 1 at full size: SD1.5-shaped UNet (859.5 M parameters), LoRA rank 4, batch 1, 256² (32×32
+    latents), fp32 — the reference's own CPU-runnable case.  The GPU path (fused kernels, slab, fused clip+AdamW) must
+    land within 1e-3 relative of the CPU oracle's LoRA state on identical seeds and inputs (north_star)."""
+    import bench
+    from harness.unet import UNet2DConditionModel, sd15_config
+
+    steps = 4
+    n_threads = bench.usable_cpus()
+    torch.set_num_threads(n_threads)
+
+    def make(device):
+        torch.manual_seed(0)
+        with torch.device(device):
+            m = UNet2DConditionModel(sd15_config())
+        m.requires_grad_(False)
+        return m
+
+    ref = make("cpu")
+    ref_params, _ = orc.inject(ref, r=4)
+    g = torch.Generator().manual_seed(1)
+    warm = [torch.randn(p.shape, generator=g) * 0.01 if i % 2 == 0 else None for i, p in enumerate(ref_params)]
+    with torch.no_grad():
+        for p, w in zip(ref_params, warm):
+            if w is not None:
+                p.copy_(w)
+    init_state = orc.flat_params(ref_params).clone()
+    ref_losses = orc.train_steps(ref, ref_params, steps, 1, 32, 77, 768, lr=1e-4)
+    want = orc.flat_params(ref_params)
+    state = {k: v for k, v in ref.state_dict().items() if "lora_" not in k}
+    del ref
+
+    unet = make("cpu")
+    unet.load_state_dict({k.replace(".linear.", "."): v for k, v in state.items()})  # same frozen weights, bit for bit
+    unet.to(DEV)
+    params, _ = dfa.inject_trainable_lora(unet, r=4)
+    plist = list(itertools.chain(*params))
+    with torch.no_grad():
+        for i, (p, rp) in enumerate(zip(plist, torch.split(init_state, [q.numel() for q in plist]))):
+            p.copy_(rp.view(p.shape).to(DEV))
+    trainer = tr.LoraTrainer(unet, lr=1e-4)
+    assert trainer.slab.numel == 1246464
+    losses = []
+    for step in range(steps):
+        latents, noise, ts, ctx = orc.synthetic_batch(step, 1, 32, 77, 768)
+        losses.append(trainer.step(latents.to(DEV), noise.to(DEV), ts.to(DEV), ctx.to(DEV)).item())
+    got = tr.flat_lora_state(unet).cpu()
+    assert relerr(torch.tensor(losses), torch.tensor(ref_losses)) < 1e-3
+    assert relerr(got, want) < 1e-3
+    assert relerr(got - init_state, want - init_state) < 2e-2  # the 4-step UPDATE itself, not just the state
