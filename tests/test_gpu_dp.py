@@ -1,0 +1,79 @@
+"""Two data-parallel ranks driving the real HIP path on ONE GPU (gloo transports the slab; RCCL itself is covered by the
+1-rank test in test_gpu_parity.py): 2 ranks × batch 2 must equal 1 rank × batch 4 — broadcast of the initial slab,
+early [up|mid] bucket from the backward hook, per-range folding of the partial sums, 1/world in the optimizer."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(rank, world, port, batch, out):
+    import itertools
+
+    import diffusion_finetuning_amd as dfa
+    from diffusion_finetuning_amd import trainer as tr
+    from oracle import lora_oracle as orc
+    from tests.conftest import build_tiny_unet
+
+    torch.set_num_threads(2)
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    unet = build_tiny_unet(seed=3).to(dev)
+    params, _ = dfa.inject_trainable_lora(unet, r=4)
+    plist = list(itertools.chain(*params))
+    g = torch.Generator().manual_seed(11 + rank)  # ranks start DIFFERENT: the broadcast must fix that
+    with torch.no_grad():
+        for i, p in enumerate(plist):
+            if i % 2 == 0:
+                p.copy_((torch.randn(p.shape, generator=g) * 0.02).to(dev))
+    trainer = tr.LoraTrainer(unet, lr=1e-3)
+    if world > 1:
+        assert trainer.exchange.active and trainer.exchange.early_range is not None
+    for step in range(3):
+        latents, noise, ts, ctx = orc.synthetic_batch(step, batch * world, 8, 6, 32)
+        sl = slice(rank * batch, (rank + 1) * batch)
+        trainer.step(latents[sl].to(dev), noise[sl].to(dev), ts[sl].to(dev), ctx[sl].to(dev))
+    state = trainer.slab.params[: trainer.slab.numel].cpu()
+    if world > 1:
+        gathered = [torch.zeros_like(state) for _ in range(world)]
+        dist.all_gather(gathered, state)
+        assert all(torch.equal(gathered[0], t) for t in gathered)  # replicas stay identical
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        out.put(state.numpy().copy())  # by value: the producer may exit before the consumer reads
+
+
+def test_two_ranks_equal_one_rank_with_double_batch():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, 2, port, 2, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    two = torch.from_numpy(q.get(timeout=300))
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    single = ctx.Process(target=_run, args=(0, 1, port, 4, q))
+    single.start()
+    one = torch.from_numpy(q.get(timeout=300))
+    single.join(timeout=300)
+    assert single.exitcode == 0
+    err = ((two - one).norm() / one.norm()).item()
+    assert err < 1e-4, err
