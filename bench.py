@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--no-prof", action="store_true", help="do not attach kernel events in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --shared-gpu rehearses N ranks on one GPU")
+    ap.add_argument("--shared-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -145,11 +147,16 @@ def main():
     import torch.distributed as dist
 
     torch.set_num_threads(max(1, usable_cpus() // max(1, world if world <= 8 else 8)))
+    if args.shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     from diffusion_finetuning_amd import _native as nat
     from diffusion_finetuning_amd.trainer import LoraTrainer
