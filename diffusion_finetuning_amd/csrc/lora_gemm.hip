@@ -17,7 +17,9 @@
 //     The XOR swizzle of the 16-B chunks is applied to the per-lane SOURCE address (the DMA writes LDS in
 //     lane order) and again on the fragment reads, which are then bank-conflict-free ds_read_b128.
 //   - fallback main loop (contraction not a multiple of the K-step): register-staged, 2 barriers per step.
-//   - base contraction on MFMA 16x16x32 (f16/bf16) or 16x16x4 (f32, exact);
+//   - base contraction on MFMA 16x16x32 (f16/bf16) or 16x16x4 (f32, exact), issued with the Bm fragment as the
+//     first operand: a lane then owns 4 CONSECUTIVE COLUMNS of one output row (and 4 consecutive rank entries of
+//     P), so the epilogue moves 8/16 bytes per LDS access instead of one element;
 //   - the rank-r factor rides along as a 16-row tile: the X fragments already in VGPRs are multiplied
 //     with it (one extra MFMA per row fragment, K-steps split between the two column waves), so T
 //     costs no extra HBM or LDS traffic for X;
@@ -49,6 +51,8 @@ struct GemmParams {
 
 constexpr int kRowBytes = 128;  // one K-step of one tile row
 constexpr int kRP = 16;         // rank padded to one MFMA fragment
+constexpr int kSPS = 20;        // fp32 row stride of the P image in LDS: 80 B keeps the 16-B row reads conflict-free
+template <typename T> struct alignas(sizeof(T) * 4) Quad { T v[4]; };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * kRowBytes + ((chunk ^ (row & 7)) << 4);
@@ -73,6 +77,21 @@ template <> struct Mfma<bf16_t> {
     }
 };
 
+#ifdef LORA_STAMPS  // diagnostic build only (tools/wg_timeline.py): per-workgroup phase timestamps
+__device__ unsigned long long g_stamps[8192 * 16];
+#define STAMP(i)                                                                  \
+    do {                                                                          \
+        if (tid == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); \
+    } while (0)
+#define STAMP_WALL(i)                                                             \
+    do {                                                                          \
+        if (tid == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 16 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define STAMP(i)
+#define STAMP_WALL(i)
+#endif
+
 // One stage of the ring / the single staging buffer: A rows, B rows, factor rows.  With counted waits (3 stages) every
 // wave must issue the same number of DMA loads per stage, so the 16 factor rows are replicated over one staging pass;
 // with the 2-stage ring every wait is vmcnt(0) and only the first two waves load the factor tile.
@@ -84,7 +103,7 @@ template <int BM, int BN, typename T, bool MAIN, int STG, int NW> constexpr int 
     constexpr int sq = MAIN ? BN * kRP * (int)sizeof(T) : 0;
     constexpr int ep = sizeof(T) == 4 ? 2 : 1;
     constexpr int sc = MAIN ? (BM / ep) * (BN * (int)sizeof(T) + 16) : 0;
-    constexpr int sp = (NW / 2) * BM * kRP * 4;
+    constexpr int sp = (NW / 2) * BM * kSPS * 4;
     constexpr int a = ring + sq;
     constexpr int b = sc > sp ? sc : sp;
     return a > b ? a : b;
@@ -123,8 +142,19 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
     const int l15 = lane & 15;
     const int lq = lane >> 4;
 
+    STAMP_WALL(0);
+    STAMP(1);
+#ifdef LORA_STAMPS
+    if (tid == 0 && blockIdx.x < 8192) {
+        g_stamps[blockIdx.x * 16 + 10] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+        g_stamps[blockIdx.x * 16 + 11] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+    }
+#endif
     // XCD-aware tile assignment: blocks b and b+8 share an XCD (round-robin dispatch), so give
     // every XCD a contiguous run of tiles; column tiles of one row panel are consecutive.
+    // Pull every kernel argument into SGPRs now: one scalar-load round trip instead of two dependent ones.
+    asm volatile("" ::"s"(p.Am), "s"(p.Bm), "s"(p.bias), "s"(p.Fp), "s"(p.Qp), "s"(p.C), "s"(p.P), "s"(p.M), "s"(p.Kc),
+                 "s"(p.Nc), "s"(p.scale), "s"(p.tiles_m), "s"(p.tiles_n), "s"(p.col_major));
     int tile;
     {
         const int total = p.tiles_m * p.tiles_n;
@@ -136,8 +166,11 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
     // Which operand should stay inside one XCD's L2?  Row-major tile order keeps a row panel of Am there and makes
     // every XCD stream all of Bm; column-major order keeps a slice of Bm there and streams Am instead.  The host
     // picks the order that re-fetches the SMALLER operand eight times (col_major when Bm is the bigger one).
-    const int tm = p.col_major ? tile % p.tiles_m : tile / p.tiles_n;
-    const int tn = p.col_major ? tile / p.tiles_m : tile - tm * p.tiles_n;
+    const unsigned inner = p.col_major ? p.tiles_m : p.tiles_n;  // tiles along the fast direction
+    const unsigned t_slow = (unsigned)tile / inner, t_fast = (unsigned)tile - t_slow * inner;
+    const int tm = p.col_major ? t_fast : t_slow;
+    const int tn = p.col_major ? t_slow : t_fast;
+    STAMP(12);
     const int64_t m0 = (int64_t)tm * BM;
     const int n0 = tn * BN;
 
@@ -170,13 +203,40 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
     if constexpr (MAIN) {
         constexpr int CPRQ = kRP * (int)sizeof(T) / 16;  // chunks per packed row (2 for 16-bit, 4 for f32)
         const T* Qg = static_cast<const T*>(p.Qp);
-        for (int idx = tid; idx < BN * CPRQ; idx += NT) {
-            const int n = idx / CPRQ, ch = idx - n * CPRQ;
-            const int nn = n0 + n < p.Nc ? n0 + n : p.Nc - 1;
-            *reinterpret_cast<Chunk<T>*>(sQ + idx * 16) =
-                *reinterpret_cast<const Chunk<T>*>(Qg + (int64_t)nn * kRP + ch * VEC);
+        if constexpr (PIPE) {
+            // asynchronous: the oldest DMA of this wave, so the main loop's first counted wait covers it
+            for (int base = wave * 64; base < BN * CPRQ; base += NT) {
+                const int idx = base + lane;
+                const int n = idx / CPRQ, ch = idx - n * CPRQ;
+                const int nn = n0 + n < p.Nc ? n0 + n : p.Nc - 1;
+                glds16(Qg + (int64_t)nn * kRP + ch * VEC, sQ + base * 16);
+            }
+        } else {
+            for (int idx = tid; idx < BN * CPRQ; idx += NT) {
+                const int n = idx / CPRQ, ch = idx - n * CPRQ;
+                const int nn = n0 + n < p.Nc ? n0 + n : p.Nc - 1;
+                *reinterpret_cast<Chunk<T>*>(sQ + idx * 16) =
+                    *reinterpret_cast<const Chunk<T>*>(Qg + (int64_t)nn * kRP + ch * VEC);
+            }
         }
     }
+
+    // bias of the lane's 4·NI output columns, fetched now so the epilogue never waits on it
+    float bias_v[MAIN ? NI : 1][4];
+    if constexpr (MAIN) {
+        if (p.bias != nullptr) {
+            const T* bias = static_cast<const T*>(p.bias);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    int col = n0 + wn * WTN + ni * 16 + lq * 4 + reg;
+                    if (col > p.Nc - 1) col = p.Nc - 1;
+                    bias_v[ni][reg] = to_f32<T>(bias[col]);
+                }
+        }
+    }
+    STAMP(13);
 
     f32x4 acc[MAIN ? MI : 1][MAIN ? NI : 1];
     f32x4 pacc[MI];
@@ -204,7 +264,7 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
                 if ((kt * 2 + ks) % WN == wn) {
                     const Frag ff = *reinterpret_cast<const Frag*>(sF + lds_off(l15, chunk));
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) pacc[mi] = Mfma<T>::run(af[mi], ff, pacc[mi]);
+                    for (int mi = 0; mi < MI; ++mi) pacc[mi] = Mfma<T>::run(ff, af[mi], pacc[mi]);
                 }
                 if constexpr (MAIN) {
                     Frag bf[NI];
@@ -214,7 +274,7 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = Mfma<T>::run(af[mi], bf[ni], acc[mi][ni]);
+                        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = Mfma<T>::run(bf[ni], af[mi], acc[mi][ni]);
                 }
             }
         } else {
@@ -233,7 +293,7 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
                         for (int mi = 0; mi < MI; ++mi)
-                            pacc[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi][e], ff[e], pacc[mi], 0, 0, 0);
+                            pacc[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(ff[e], af[mi][e], pacc[mi], 0, 0, 0);
                 }
                 if constexpr (MAIN) {
                     f32x4 bf[NI];
@@ -246,7 +306,7 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
                         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                             for (int ni = 0; ni < NI; ++ni)
-                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi][e], bf[ni][e],
+                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[ni][e], af[mi][e],
                                                                                   acc[mi][ni], 0, 0, 0);
                 }
             }
@@ -274,6 +334,7 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
         constexpr int DIST = kStages - 1;  // K-steps in flight ahead of the one being multiplied
         issue(0, 0);
         if (DIST > 1 && nk > 1) issue(1, 1);
+        STAMP(2);
         int buf = 0;
         for (int kt = 0; kt < nk; ++kt) {
             // stage kt has landed for this wave once only the loads of the stages issued after it are outstanding
@@ -283,6 +344,7 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __builtin_amdgcn_s_barrier();  // every wave's part of stage kt is in; stage kt-1 is fully read
+            if (kt == 0) STAMP(3);
             if (kt + DIST < nk) issue(kt + DIST, buf >= 1 ? buf - 1 : kStages - 1);  // refill the buffer read last step
             compute(smem + buf * STAGE, kt);
             buf = buf + 1 == kStages ? 0 : buf + 1;
@@ -338,15 +400,14 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
         }
     }
 
+    STAMP(4);
     // ---- epilogue 1: combine the two partial P tiles through LDS --------------------------
     __syncthreads();
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int row = wm * (BM / 2) + mi * 16 + lq * 4 + reg;
-            sP[(wn * BM + row) * kRP + l15] = pacc[mi][reg];
-        }
+    for (int mi = 0; mi < MI; ++mi) {
+        const int row = wm * (BM / 2) + mi * 16 + l15;
+        *reinterpret_cast<f32x4*>(&sP[(wn * BM + row) * kSPS + lq * 4]) = pacc[mi];
+    }
     __syncthreads();
 
     if (p.P != nullptr && tn == 0) {
@@ -358,13 +419,14 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
                 if (j < p.r) {
                     float v = 0.f;
 #pragma unroll
-                    for (int w = 0; w < WN; ++w) v += sP[(w * BM + row) * kRP + j];
+                    for (int w = 0; w < WN; ++w) v += sP[(w * BM + row) * kSPS + j];
                     p.P[(m0 + row) * p.r + j] = v;
                 }
             }
         }
     }
 
+    STAMP(5);
     if constexpr (MAIN) {
         // ---- epilogue 2: acc += s·P·Qᵀ as one extra MFMA K-step ---------------------------
         if constexpr (!F32) {
@@ -375,22 +437,32 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
             for (int ni = 0; ni < NI; ++ni)
                 qf[ni] = *reinterpret_cast<const Frag*>(
                     sQ + ((wn * WTN + ni * 16 + l15) * kRP + j0) * (int)sizeof(T));
+            f32x4 pimg[MI][WN][2];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 const int row = wm * (BM / 2) + mi * 16 + l15;
+#pragma unroll
+                for (int w = 0; w < WN; ++w) {
+                    const f32x4* src = reinterpret_cast<const f32x4*>(&sP[(w * BM + row) * kSPS + j0]);
+                    pimg[mi][w][0] = src[0];
+                    pimg[mi][w][1] = src[1];
+                }
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
                 Frag pf;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float v = 0.f;
 #pragma unroll
-                    for (int w = 0; w < WN; ++w) v += sP[(w * BM + row) * kRP + j0 + e];
+                    for (int w = 0; w < WN; ++w) v += pimg[mi][w][e >> 2][e & 3];
                     v *= p.scale;
                     const T hi = from_f32<T>(v);
                     const T lo = from_f32<T>(v - to_f32<T>(hi));
                     pf[e] = lq < 2 ? hi : lo;
                 }
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = Mfma<T>::run(pf, qf[ni], acc[mi][ni]);
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = Mfma<T>::run(qf[ni], pf, acc[mi][ni]);
             }
         } else {
             const float* q = reinterpret_cast<const float*>(sQ);
@@ -405,28 +477,24 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
                     const int row = wm * (BM / 2) + mi * 16 + l15;
                     float pv = 0.f;
 #pragma unroll
-                    for (int w = 0; w < WN; ++w) pv += sP[(w * BM + row) * kRP + j];
+                    for (int w = 0; w < WN; ++w) pv += sP[(w * BM + row) * kSPS + j];
                     pv *= p.scale;
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, qv[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[ni], pv, acc[mi][ni], 0, 0, 0);
                 }
             }
         }
 
+        STAMP(6);
         // ---- epilogue 3: bias (fp32), transpose through LDS, 16-B row stores -------------
         if (p.bias != nullptr) {
-            const T* bias = static_cast<const T*>(p.bias);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                int col = n0 + wn * WTN + ni * 16 + l15;
-                if (col > p.Nc - 1) col = p.Nc - 1;
-                const float bv = to_f32<T>(bias[col]);
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
+                for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) acc[mi][ni][reg] += bv;
-            }
+                    for (int mi = 0; mi < MI; ++mi) acc[mi][ni][reg] += bias_v[ni][reg];
         }
         constexpr int EP = F32 ? 2 : 1;
         constexpr int ROWS = BM / EP;
@@ -440,26 +508,39 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
+                    for (int ni = 0; ni < NI; ++ni) {
+                        // the lane owns 4 consecutive columns of one row: one 8-/16-byte LDS write
+                        const int row = (EP == 1 ? wm * (BM / 2) : 0) + mi * 16 + l15;
+                        const int col = wn * WTN + ni * 16 + lq * 4;
+                        Quad<T> q;
 #pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) {
-                            const int row = (EP == 1 ? wm * (BM / 2) : 0) + mi * 16 + lq * 4 + reg;
-                            const int col = wn * WTN + ni * 16 + l15;
-                            *reinterpret_cast<T*>(smem + row * SC_STRIDE + col * (int)sizeof(T)) =
-                                from_f32<T>(acc[mi][ni][reg]);
-                        }
+                        for (int reg = 0; reg < 4; ++reg) q.v[reg] = from_f32<T>(acc[mi][ni][reg]);
+                        *reinterpret_cast<Quad<T>*>(smem + row * SC_STRIDE + col * (int)sizeof(T)) = q;
+                    }
             }
             __syncthreads();
-            for (int idx = tid; idx < ROWS * CPR; idx += NT) {
+            STAMP(7);
+            constexpr int NST = ROWS * CPR / NT;  // 16-B chunks per thread
+            static_assert(ROWS * CPR % NT == 0, "tile rows must split evenly over the threads");
+            Chunk<T> out[NST];
+#pragma unroll
+            for (int i = 0; i < NST; ++i) {
+                const int idx = tid + i * NT;
+                const int row = idx / CPR, ch = idx - row * CPR;
+                out[i] = *reinterpret_cast<const Chunk<T>*>(smem + row * SC_STRIDE + ch * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < NST; ++i) {
+                const int idx = tid + i * NT;
                 const int row = idx / CPR, ch = idx - row * CPR;
                 const int64_t m = m0 + ep * ROWS + row;
                 const int col = n0 + ch * VEC;
-                if (m < p.M && col < p.Nc)
-                    *reinterpret_cast<Chunk<T>*>(Cg + m * p.Nc + col) =
-                        *reinterpret_cast<const Chunk<T>*>(smem + row * SC_STRIDE + ch * 16);
+                if (m < p.M && col < p.Nc) *reinterpret_cast<Chunk<T>*>(Cg + m * p.Nc + col) = out[i];
             }
         }
     }
+    STAMP(8);
+    STAMP_WALL(9);
 }
 
 // Shape-agnostic path (unaligned sizes or r > 16): correct, not fast.  F/Q read as fp32 masters.
@@ -664,6 +745,17 @@ int check_common(int64_t M, int K, int N, int r, int dtype) {
 double esize(int dtype) { return dtype == LORA_F32 ? 4.0 : 2.0; }
 
 }  // namespace
+
+#ifdef LORA_STAMPS
+extern "C" int lora_debug_stamps(unsigned long long* host_out, int n_words) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), (size_t)n_words * 8) == hipSuccess ? 0 : -1;
+}
+extern "C" int lora_debug_stamps_reset() {
+    void* d = nullptr;
+    if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_stamps)) != hipSuccess) return -1;
+    return hipMemset(d, 0, sizeof(g_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int lora_pack_factors(const float* A, const float* B, void* Apack, void* Bpack, int K, int N, int r,
                                  int dtype, void* stream) {

@@ -1,0 +1,89 @@
+"""Dev tool: where does a workgroup of the fused GEMM spend its time?
+
+Builds a DIAGNOSTIC copy of the library with -DLORA_STAMPS (per-workgroup cycle-counter stamps at the phase
+boundaries of lora_gemm_kernel), launches one forward per shape and prints the phase durations (median over
+workgroups, in µs of the 100 MHz wall clock / shader cycles) plus the launch ramp (first/last start, last end).
+Never used by the product path.  usage: python tools/wg_timeline.py [M K N]..."""
+import ctypes
+import os
+import subprocess
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from diffusion_finetuning_amd import build_native as bn
+
+OUT = os.path.join(bn.LIB_DIR, "liblora_hip_stamps.so")
+
+
+def build():
+    srcs = [os.path.join(bn.CSRC, s) for s in bn.SOURCES]
+    cmd = [bn.HIPCC, *bn.FLAGS, "-DLORA_STAMPS", "-shared", "-o", OUT, *srcs]
+    subprocess.run(cmd, check=True)
+
+
+def main():
+    if not os.path.exists(OUT) or "--rebuild" in sys.argv:
+        build()
+    lib = ctypes.CDLL(OUT)
+    vp, i64, ci, cf = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+    lib.lora_linear_fwd.argtypes = [vp] * 9 + [i64, ci, ci, ci, cf, ci, vp]
+    lib.lora_pack_factors.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
+    lib.lora_debug_stamps.argtypes = [vp, ci]
+    args = [int(a) for a in sys.argv[1:] if a.lstrip("-").isdigit()]
+    shapes = [tuple(args[i:i + 3]) for i in range(0, len(args), 3)] or [
+        (16384, 320, 320), (4096, 640, 640), (16384, 320, 2560), (16384, 1280, 320), (1024, 1280, 1280)]
+    dev = "cuda"
+    for (M, K, N) in shapes:
+        x = torch.randn(M, K, device=dev).half()
+        w = (torch.randn(N, K, device=dev) / K ** 0.5).half()
+        a = torch.randn(4, K, device=dev) / 4
+        b = torch.randn(N, 4, device=dev) * 0.05
+        ap = torch.zeros(2 * 16 * K, device=dev, dtype=torch.float16)
+        bp = torch.zeros(2 * 16 * N, device=dev, dtype=torch.float16)
+        y = torch.empty(M, N, device=dev, dtype=torch.float16)
+        t = torch.empty(M, 4, device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+        assert lib.lora_pack_factors(a.data_ptr(), b.data_ptr(), ap.data_ptr(), bp.data_ptr(), K, N, 4, 1, st) == 0
+
+        def launch():
+            rc = lib.lora_linear_fwd(x.data_ptr(), w.data_ptr(), None, a.data_ptr(), b.data_ptr(), ap.data_ptr(),
+                                     bp.data_ptr(), y.data_ptr(), t.data_ptr(), M, K, N, 4, 1.0, 1, st)
+            assert rc == 0
+
+        for _ in range(3):
+            launch()
+        torch.cuda.synchronize()
+        assert lib.lora_debug_stamps_reset() == 0
+        launch()
+        torch.cuda.synchronize()
+        buf = np.zeros(8192 * 16, dtype=np.uint64)
+        assert lib.lora_debug_stamps(buf.ctypes.data, buf.size) == 0
+        s = buf.reshape(8192, 16).astype(np.int64)
+        live = s[:, 0] > 0
+        s = s[live]
+        n = len(s)
+        wall0 = s[:, 0].min()
+        start_us = (s[:, 0] - wall0) / 100.0
+        end_us = (s[:, 9] - wall0) / 100.0
+        cyc = s[:, [1, 12, 13, 2, 3, 4, 5, 6, 7, 8]]
+        ph = np.diff(cyc, axis=1)  # cycles per phase
+        # calibrate cycles -> µs with the wall clock of the same workgroups
+        dur_cyc = (cyc[:, -1] - cyc[:, 0]).astype(float)
+        dur_us = (s[:, 9] - s[:, 0]) / 100.0
+        k = np.median(dur_cyc[dur_us > 0] / dur_us[dur_us > 0])
+        names = ["kernarg+tile index", "addresses+Q dma+bias", "issue stages", "first stage lands", "main loop", "P combine", "LoRA mfma", "C->LDS", "C stores"]
+        print(f"--- {M}x{K}x{N}: {n} workgroups, {k:.0f} cycles/us; kernel span {end_us.max():.2f} us "
+              f"(starts {start_us.min():.2f}..{np.percentile(start_us, 50):.2f}..{start_us.max():.2f}, "
+              f"WG life median {np.median(dur_us):.2f} max {dur_us.max():.2f})")
+        for i, nm in enumerate(names):
+            v = ph[:, i] / k
+            print(f"    {nm:18s} median {np.median(v):6.2f} us   p90 {np.percentile(v, 90):6.2f}   max {v.max():6.2f}")
+        xcc = s[:, 11] & 0xF
+        cu = s[:, 10]
+        print(f"    distinct (xcc,hw_id>>8&0xff) slots: {len(set(zip(xcc.tolist(), ((cu >> 8) & 0xFF).tolist())))}")
+
+
+main()
