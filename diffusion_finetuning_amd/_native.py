@@ -55,6 +55,10 @@ SIGNATURES = {
     "geglu_gate_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "attn_split_heads": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "attn_merge_heads": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "attn_ctx_supported": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32]),
+    "attn_ctx_fwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "attn_ctx_bwd_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
+    "attn_ctx_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "lora_prof_enable": (_i32, [_i32]),
     "lora_prof_collect": (_i32, [ctypes.POINTER(ProfTotals)]),
     "lora_prof_kernel_name": (ctypes.c_char_p, [_i32]),
@@ -367,6 +371,39 @@ def attn_merge_heads(x4, d: int):
     _check(lib().attn_merge_heads(_ptr(x4), _ptr(out), B, N, H, d, D, dtype_code(x4.dtype), _stream(x4)),
            "attn_merge_heads")
     return out
+
+
+def attn_ctx_supported(B: int, Tq: int, Tk: int, H: int, d: int, dtype) -> bool:
+    if dtype not in (torch.float16, torch.bfloat16):
+        return False
+    return bool(lib().attn_ctx_supported(B, Tq, Tk, H, d, dtype_code(dtype)))
+
+
+def attn_ctx_fwd(q, k, v, heads: int, scale: float):
+    """q [B,Tq,H·d], k/v [B,Tk,H·d] contiguous → softmax(q·kᵀ·scale)·v per head, [B,Tq,H·d]."""
+    _require_device(q, k, v)
+    B, Tq, HD = q.shape
+    Tk = k.shape[1]
+    out = torch.empty_like(q)
+    _check(lib().attn_ctx_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, Tq, Tk, heads, HD // heads, float(scale),
+                              dtype_code(q.dtype), _stream(q)), "attn_ctx_fwd")
+    return out
+
+
+def attn_ctx_bwd(q, k, v, dout, heads: int, scale: float):
+    """→ (dq, dk, dv), same layouts as the inputs."""
+    _require_device(q, k, v, dout)
+    B, Tq, HD = q.shape
+    Tk = k.shape[1]
+    d = HD // heads
+    nbytes = lib().attn_ctx_bwd_workspace_bytes(B, Tq, Tk, heads, d)
+    if nbytes < 0:
+        raise RuntimeError("attn_ctx_bwd: unsupported shape")
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=q.device)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    _check(lib().attn_ctx_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(dout), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(ws), B, Tq, Tk,
+                              heads, d, float(scale), dtype_code(q.dtype), _stream(q)), "attn_ctx_bwd")
+    return dq, dk, dv
 
 
 def prof_enable(capacity: int) -> None:

@@ -1,0 +1,609 @@
+// Short-context attention core for gfx950:  O = softmax(Q·Kᵀ·scale)·V  per head, for key/value sequences of at
+// most 128 tokens — the cross-attention (`attn2`) of every transformer block, whose keys/values are the 77 text
+// tokens (the op sandwiched between the to_q/to_k/to_v and to_out LoRA linears; diffusers
+// CrossAttention.forward, the caller of the layers wrapped at lora_diffusion/lora.py:137-183).
+//
+// Why a dedicated kernel: with so few keys the whole K and V of a head fit in LDS, there is ONE key tile (no online
+// softmax, no saved log-sum-exp), and the op is a streaming pass over Q (and dO): HBM-bound.  The generic
+// flash-attention backward parallelises over key blocks and has one or two of them here, which leaves the chip idle
+// (MI355X, 4 × 4096 queries × 77 keys, 8 heads of 40: ~190 µs backward for ~30 MB of traffic).
+//
+// Layout: Q/O/dO/dQ are [B, Tq, H·d] and K/V/dK/dV [B, Tk, H·d] — exactly what the LoRA linears produce and
+// consume, so no head split/merge copies.  Each workgroup (4 waves) owns one (batch, head) and a chunk of query
+// rows; a wave works on blocks of 16 query rows with MFMA 16x16x32:
+//   Sᵀ = K·Qᵀ  with the K fragment as the FIRST operand, so a lane owns one query row and 4 consecutive keys per
+//   fragment: the softmax row reductions are in-lane plus two cross-lane steps, and the probability registers are
+//   directly the second operand of the next product (contraction over keys) — P never goes through LDS.  V (and K
+//   for dQ) sit in LDS transposed with the keys permuted to match that register order.
+// Backward recomputes P from Q and K (cheap: one tile), uses Σ_key P·dP for the softmax correction (so O is not
+// needed), writes dQ directly, and accumulates dK/dV over the chunk in registers (MFMA 16x16x16, contraction over the
+// 16 query rows; P, dS, Q and dO are re-read transposed from small per-wave LDS tiles for that).  Per-workgroup fp32 partials are
+// summed in a fixed order by a small second kernel: deterministic, no atomics.
+#include "common.h"
+
+namespace {
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Mma;
+template <> struct Mma<half_t> {
+    using F8 = f16x8;
+    static __device__ __forceinline__ f32x4 k32(F8 a, F8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 k16(const half_t* a, const half_t* b, f32x4 c) {
+        const f16x4 av = {a[0], a[1], a[2], a[3]}, bv = {b[0], b[1], b[2], b[3]};
+        return __builtin_amdgcn_mfma_f32_16x16x16f16(av, bv, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<bf16_t> {
+    using F8 = bf16x8;
+    static __device__ __forceinline__ f32x4 k32(F8 a, F8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 k16(const bf16_t* a, const bf16_t* b, f32x4 c) {
+        s16x4 av, bv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            av[e] = __builtin_bit_cast(short, a[e]);
+            bv[e] = __builtin_bit_cast(short, b[e]);
+        }
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bv, c, 0, 0, 0);
+    }
+};
+
+template <typename T> struct alignas(8) Quad4 { T v[4]; };
+
+// position of a key inside the permuted key axis: fragments 2k and 2k+1 interleave in groups of four, which is the
+// order in which a lane's accumulator registers of two neighbouring S fragments form one 8-wide MFMA operand
+__device__ __forceinline__ int key_pos(int key) {
+    return (key & ~31) | (((key >> 2) & 3) << 3) | (((key >> 4) & 1) << 2) | (key & 3);
+}
+
+template <int KS, int DF, int NKF> struct CtxShape {
+    static constexpr int DP = KS * 32;       // head dim padded for the Q·Kᵀ contraction
+    static constexpr int DV = DF * 16;       // head dim padded as an MFMA output extent
+    static constexpr int NK = NKF * 16;      // keys padded
+    static constexpr int KROW = DP + 8;      // LDS row strides (halfs), +16 B against bank conflicts
+    static constexpr int TROW = NK + 8;
+};
+
+// 16-byte load that is never predicated (a predicated load costs a branch and a full wait per load on this
+// compiler): the caller passes an address that is valid either way, the value is zeroed afterwards when !ok
+template <typename T> __device__ __forceinline__ Chunk<T> load_or_zero(const T* p, bool ok) {
+    Chunk<T> v = *reinterpret_cast<const Chunk<T>*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v.v[e] = ok ? v.v[e] : from_f32<T>(0.f);
+    return v;
+}
+
+// K (or V) of one (batch, head) → registers: thread owns chunks idx = tid + i*256 of the [NK][DP/8] chunk grid
+template <typename T, int KS, int DF, int NKF> struct StageRegs {
+    using S = CtxShape<KS, DF, NKF>;
+    static constexpr int CPR = S::DP / 8;
+    static constexpr int N = S::NK * CPR;
+    static constexpr int IT = (N + 255) / 256;
+    Chunk<T> v[IT];
+    __device__ __forceinline__ void load(const T* src, int64_t row_stride, int Tk, int d) {
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            const int key = idx / CPR, c = (idx - key * CPR) * 8;
+            const bool ok = idx < N && key < Tk && c < d;
+            v[i] = load_or_zero<T>(ok ? src + key * row_stride + c : src, ok);
+        }
+    }
+    // row-major [NK][KROW] (operand rows = keys), zero beyond Tk and d
+    __device__ __forceinline__ void store_rows(T* dst) const {
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            const int key = idx / CPR, c = (idx - key * CPR) * 8;
+            if (idx < N) *reinterpret_cast<Chunk<T>*>(dst + key * S::KROW + c) = v[i];
+        }
+    }
+    // transposed [DV][TROW] with the keys permuted (operand rows = head dim, contraction over keys)
+    __device__ __forceinline__ void store_transposed(T* dst) const {
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            const int key = idx / CPR, c = (idx - key * CPR) * 8;
+            if (idx < N && c < S::DV) {
+                const int pos = key_pos(key);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dst[(c + e) * S::TROW + pos] = v[i].v[e];
+            }
+        }
+    }
+};
+
+// row fragments (second MFMA operand: lane = (row l15, 8 consecutive head-dim values at ks*32 + lq*8)).
+// `safe` is any valid address of the tensor: rows past the end are read from there and zeroed.
+template <typename T, int KS>
+__device__ __forceinline__ void load_row_frags(const T* base, const T* safe, bool valid, int d, int lq,
+                                               typename Mma<T>::F8 (&f)[KS]) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int c = ks * 32 + lq * 8;
+        const bool ok = valid && c < d;
+        const Chunk<T> v = load_or_zero<T>(ok ? base + c : safe, ok);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[ks][e] = v.v[e];
+    }
+}
+
+// softmax over the keys of one query row held as Sᵀ accumulators (lane = query l15; keys nf*16 + lq*4 + r).
+// In: raw scores.  Out: normalised probabilities in place; returns the row max (log2 domain) and 1/sum.
+template <int NKF>
+__device__ __forceinline__ void softmax_rows(f32x4 (&s)[NKF], int lq, int Tk, float scale_log2e, float& m, float& inv_l) {
+    m = -INFINITY;
+#pragma unroll
+    for (int nf = 0; nf < NKF; ++nf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = nf * 16 + lq * 4 + r;
+            const float v = key < Tk ? s[nf][r] * scale_log2e : -INFINITY;
+            s[nf][r] = v;
+            m = fmaxf(m, v);
+        }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int nf = 0; nf < NKF; ++nf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = exp2f(s[nf][r] - m);  // exp2f(-inf) = 0 for masked keys
+            s[nf][r] = p;
+            l += p;
+        }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    inv_l = 1.f / l;
+#pragma unroll
+    for (int nf = 0; nf < NKF; ++nf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[nf][r] *= inv_l;
+}
+
+// two neighbouring accumulator fragments → one 8-wide operand over 32 (permuted) keys
+template <typename T>
+__device__ __forceinline__ typename Mma<T>::F8 pair_frag(const f32x4& a, const f32x4& b) {
+    typename Mma<T>::F8 f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f[e] = from_f32<T>(a[e]);
+        f[4 + e] = from_f32<T>(b[e]);
+    }
+    return f;
+}
+
+template <typename T, int KS, int DF, int NKF>
+__global__ __launch_bounds__(256) void attn_ctx_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
+                                                            const T* __restrict__ V, T* __restrict__ O, int Tq, int Tk,
+                                                            int H, int d, float scale_log2e, int rq, int chunks) {
+    using S = CtxShape<KS, DF, NKF>;
+    using F8 = typename Mma<T>::F8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Ks = reinterpret_cast<T*>(smem);          // [NK][KROW]
+    T* Vt = Ks + S::NK * S::KROW;                 // [DV][TROW]
+
+    const int chunk = blockIdx.x % chunks;
+    const int bh = blockIdx.x / chunks;
+    const int b = bh / H, h = bh - b * H;
+    const int64_t HD = (int64_t)H * d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    {
+        StageRegs<T, KS, DF, NKF> kr, vr;  // both tensors in flight before the first LDS write
+        kr.load(K + (int64_t)b * Tk * HD + h * d, HD, Tk, d);
+        vr.load(V + (int64_t)b * Tk * HD + h * d, HD, Tk, d);
+        kr.store_rows(Ks);
+        vr.store_transposed(Vt);
+    }
+    __syncthreads();
+
+    const int row_end = min(Tq, (chunk + 1) * rq);
+    const T* Qh = Q + (int64_t)b * Tq * HD + h * d;
+    F8 qf[KS];
+    {
+        const int t = chunk * rq + wave * 16 + l15;
+        load_row_frags<T, KS>(Qh + (int64_t)t * HD, Qh, t < row_end, d, lq, qf);
+    }
+    for (int t0 = chunk * rq + wave * 16; t0 < row_end; t0 += 64) {
+        const int t = t0 + l15;
+        const bool valid = t < row_end;
+        F8 qn[KS];  // next block's rows: in flight while this block is computed
+        load_row_frags<T, KS>(Qh + (int64_t)(t + 64) * HD, Qh, t + 64 < row_end, d, lq, qn);
+
+        f32x4 s[NKF];
+#pragma unroll
+        for (int nf = 0; nf < NKF; ++nf) {
+            s[nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const F8 kf = *reinterpret_cast<const F8*>(Ks + (nf * 16 + l15) * S::KROW + ks * 32 + lq * 8);
+                s[nf] = Mma<T>::k32(kf, qf[ks], s[nf]);
+            }
+        }
+        float m, inv_l;
+        softmax_rows<NKF>(s, lq, Tk, scale_log2e, m, inv_l);
+
+        F8 pf[NKF / 2];
+#pragma unroll
+        for (int kk = 0; kk < NKF / 2; ++kk) pf[kk] = pair_frag<T>(s[2 * kk], s[2 * kk + 1]);
+
+        T* orow = O + ((int64_t)b * Tq + t) * HD + h * d;
+#pragma unroll
+        for (int df = 0; df < DF; ++df) {
+            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < NKF / 2; ++kk) {
+                const F8 vf = *reinterpret_cast<const F8*>(Vt + (df * 16 + l15) * S::TROW + kk * 32 + lq * 8);
+                o = Mma<T>::k32(vf, pf[kk], o);
+            }
+            const int c = df * 16 + lq * 4;  // the lane owns head-dim values c..c+3 of query row t
+            if (valid && c < d) {
+                Quad4<T> out;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out.v[r] = from_f32<T>(o[r]);
+                *reinterpret_cast<Quad4<T>*>(orow + c) = out;
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];
+    }
+}
+
+// transposed fragments for the contraction over the 16 query rows: lane = (head-dim column l15, rows lq*4 .. +3),
+// read from the wave's own LDS copy of the block's rows ([16][KROW], zero beyond the valid rows and d)
+template <typename T, int DF, int KROW>
+__device__ __forceinline__ void load_col_frags(const T* tile, int l15, int lq, T (&f)[DF][4]) {
+#pragma unroll
+    for (int df = 0; df < DF; ++df)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[df][e] = tile[(lq * 4 + e) * KROW + df * 16 + l15];
+}
+
+template <typename T, int KS, int DF, int NKF>
+__global__ __launch_bounds__(256) void attn_ctx_bwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
+                                                            const T* __restrict__ V, const T* __restrict__ dO,
+                                                            T* __restrict__ dQ, float* __restrict__ part, int Tq,
+                                                            int Tk, int H, int d, float scale, float scale_log2e,
+                                                            int rq, int chunks) {
+    using S = CtxShape<KS, DF, NKF>;
+    using F8 = typename Mma<T>::F8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Ks = reinterpret_cast<T*>(smem);          // [NK][KROW]   rows = keys, for Sᵀ and S
+    T* Vs = Ks + S::NK * S::KROW;                 // [NK][KROW]   rows = keys, for dPᵀ and dP
+    T* Kt = Vs + S::NK * S::KROW;                 // [DV][TROW]   for dQ
+    T* Qw = Kt + S::DV * S::TROW + (threadIdx.x >> 6) * 2 * 16 * S::KROW;  // this wave's [16][KROW] copy of its Q rows
+    T* Gw = Qw + 16 * S::KROW;                    //                            ... and of its dO rows
+    T* Pw = Kt + S::DV * S::TROW + 4 * 2 * 16 * S::KROW + (threadIdx.x >> 6) * 2 * 16 * S::TROW;  // wave's P  [16][TROW]
+    T* Sw = Pw + 16 * S::TROW;                                                                      // wave's dS [16][TROW]
+    float* red = reinterpret_cast<float*>(smem);  // overlay after the main loop: [2][NK][DV]
+
+    const int chunk = blockIdx.x % chunks;
+    const int bh = blockIdx.x / chunks;
+    const int b = bh / H, h = bh - b * H;
+    const int64_t HD = (int64_t)H * d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    {
+        StageRegs<T, KS, DF, NKF> kr, vr;
+        kr.load(K + (int64_t)b * Tk * HD + h * d, HD, Tk, d);
+        vr.load(V + (int64_t)b * Tk * HD + h * d, HD, Tk, d);
+        kr.store_rows(Ks);
+        kr.store_transposed(Kt);
+        vr.store_rows(Vs);
+    }
+    __syncthreads();
+
+    f32x4 dk[NKF][DF], dv[NKF][DF];  // lane = head-dim column l15 of fragment df; keys nf*16 + lq*4 + r
+#pragma unroll
+    for (int nf = 0; nf < NKF; ++nf)
+#pragma unroll
+        for (int df = 0; df < DF; ++df) dk[nf][df] = dv[nf][df] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int row_end = min(Tq, (chunk + 1) * rq);
+    F8 qf[KS], gf[KS];
+    {
+        const int t = chunk * rq + wave * 16 + l15;
+        const int64_t roff = ((int64_t)b * Tq + t) * HD + h * d;
+        load_row_frags<T, KS>(Q + roff, Q, t < row_end, d, lq, qf);
+        load_row_frags<T, KS>(dO + roff, dO, t < row_end, d, lq, gf);
+    }
+    for (int t0 = chunk * rq + wave * 16; t0 < row_end; t0 += 64) {
+        const int t = t0 + l15;
+        const bool valid = t < row_end;
+        const int64_t roff = ((int64_t)b * Tq + t) * HD + h * d;
+        // this block's rows into the wave's LDS tiles (source of the transposed operands below) ...
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            *reinterpret_cast<F8*>(Qw + l15 * S::KROW + ks * 32 + lq * 8) = qf[ks];
+            *reinterpret_cast<F8*>(Gw + l15 * S::KROW + ks * 32 + lq * 8) = gf[ks];
+        }
+        // ... and the next block's rows into flight
+        F8 qn[KS], gn[KS];
+        load_row_frags<T, KS>(Q + roff + 64 * HD, Q, t + 64 < row_end, d, lq, qn);
+        load_row_frags<T, KS>(dO + roff + 64 * HD, dO, t + 64 < row_end, d, lq, gn);
+
+        // ---- query-per-lane layout: P, dP, the softmax correction, dS → dQ ----------------
+        f32x4 s[NKF], dp[NKF];
+#pragma unroll
+        for (int nf = 0; nf < NKF; ++nf) {
+            s[nf] = dp[nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int off = (nf * 16 + l15) * S::KROW + ks * 32 + lq * 8;
+                s[nf] = Mma<T>::k32(*reinterpret_cast<const F8*>(Ks + off), qf[ks], s[nf]);
+                dp[nf] = Mma<T>::k32(*reinterpret_cast<const F8*>(Vs + off), gf[ks], dp[nf]);
+            }
+        }
+        float m, inv_l;
+        softmax_rows<NKF>(s, lq, Tk, scale_log2e, m, inv_l);
+        // P in the permuted key order, one row per query: re-read below with the keys along the lanes
+#pragma unroll
+        for (int kk = 0; kk < NKF / 2; ++kk)
+            *reinterpret_cast<F8*>(Pw + l15 * S::TROW + kk * 32 + lq * 8) = pair_frag<T>(s[2 * kk], s[2 * kk + 1]);
+        float corr = 0.f;  // Σ_key P·dP  (= Σ_c dO·O of this query row)
+#pragma unroll
+        for (int nf = 0; nf < NKF; ++nf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) corr += s[nf][r] * dp[nf][r];
+        corr += __shfl_xor(corr, 16, 64);
+        corr += __shfl_xor(corr, 32, 64);
+#pragma unroll
+        for (int nf = 0; nf < NKF; ++nf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[nf][r] = s[nf][r] * (dp[nf][r] - corr) * scale;  // dS
+        {
+            F8 dsf[NKF / 2];
+#pragma unroll
+            for (int kk = 0; kk < NKF / 2; ++kk) {
+                dsf[kk] = pair_frag<T>(s[2 * kk], s[2 * kk + 1]);
+                *reinterpret_cast<F8*>(Sw + l15 * S::TROW + kk * 32 + lq * 8) = dsf[kk];
+            }
+#pragma unroll
+            for (int df = 0; df < DF; ++df) {
+                f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < NKF / 2; ++kk) {
+                    const F8 kf = *reinterpret_cast<const F8*>(Kt + (df * 16 + l15) * S::TROW + kk * 32 + lq * 8);
+                    g = Mma<T>::k32(kf, dsf[kk], g);
+                }
+                const int c = df * 16 + lq * 4;
+                if (valid && c < d) {
+                    Quad4<T> out;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) out.v[r] = from_f32<T>(g[r]);
+                    *reinterpret_cast<Quad4<T>*>(dQ + roff + c) = out;
+                }
+            }
+        }
+
+        // ---- dK, dV: contraction over the 16 query rows.  Operands with the keys (resp. head-dim columns) along the
+        // lanes and 4 query rows per lane, read back transposed from the wave's LDS tiles --------------------------
+        T qT[DF][4], gT[DF][4];
+        load_col_frags<T, DF, S::KROW>(Qw, l15, lq, qT);
+        load_col_frags<T, DF, S::KROW>(Gw, l15, lq, gT);
+#pragma unroll
+        for (int nf = 0; nf < NKF; ++nf) {
+            const int pos = (nf >> 1) * 32 + ((l15 >> 2) << 3) + (nf & 1) * 4 + (l15 & 3);  // key_pos(nf*16 + l15)
+            T pa[4], dsa[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pa[e] = Pw[(lq * 4 + e) * S::TROW + pos];
+                dsa[e] = Sw[(lq * 4 + e) * S::TROW + pos];
+            }
+#pragma unroll
+            for (int df = 0; df < DF; ++df) {
+                dv[nf][df] = Mma<T>::k16(pa, gT[df], dv[nf][df]);
+                dk[nf][df] = Mma<T>::k16(dsa, qT[df], dk[nf][df]);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[ks] = qn[ks];
+            gf[ks] = gn[ks];
+        }
+    }
+
+    // ---- sum the four waves' dK/dV through LDS in wave order, then one fp32 partial per workgroup ----------
+    __syncthreads();  // staging buffers are dead
+    // LDS image in fragment order — [tensor][nf][df][lane][r] — so every lane moves whole 16-byte accumulators
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+            f32x4* rk = reinterpret_cast<f32x4*>(red) + lane;
+            f32x4* rv = rk + NKF * DF * 64;
+            if (w == 0) {
+#pragma unroll
+                for (int nf = 0; nf < NKF; ++nf)
+#pragma unroll
+                    for (int df = 0; df < DF; ++df) {
+                        rk[(nf * DF + df) * 64] = dk[nf][df];
+                        rv[(nf * DF + df) * 64] = dv[nf][df];
+                    }
+            } else {
+#pragma unroll
+                for (int nf = 0; nf < NKF; ++nf)
+#pragma unroll
+                    for (int df = 0; df < DF; ++df) {
+                        dk[nf][df] += rk[(nf * DF + df) * 64];
+                        dv[nf][df] += rv[(nf * DF + df) * 64];
+                    }
+#pragma unroll
+                for (int nf = 0; nf < NKF; ++nf)
+#pragma unroll
+                    for (int df = 0; df < DF; ++df) {
+                        rk[(nf * DF + df) * 64] = dk[nf][df];
+                        rv[(nf * DF + df) * 64] = dv[nf][df];
+                    }
+            }
+        }
+        __syncthreads();
+    }
+    float* out = part + (int64_t)blockIdx.x * 2 * S::NK * S::DV;
+    for (int idx = threadIdx.x * 4; idx < 2 * S::NK * S::DV; idx += 1024)
+        *reinterpret_cast<f32x4*>(out + idx) = *reinterpret_cast<const f32x4*>(red + idx);
+}
+
+// dK/dV [B, Tk, H·d] = Σ_chunk partials, summed in chunk order (deterministic), cast to T
+template <typename T>
+__global__ __launch_bounds__(256) void attn_ctx_reduce_kernel(const float* __restrict__ part, T* __restrict__ dK,
+                                                               T* __restrict__ dV, int B, int Tk, int H, int d,
+                                                               int chunks, int NK, int DV) {
+    const int64_t total = (int64_t)B * Tk * H * d;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % d);
+        const int h = (int)((i / d) % H);
+        const int key = (int)((i / ((int64_t)d * H)) % Tk);
+        const int b = (int)(i / ((int64_t)d * H * Tk));
+        // fragment order [nf][df][lane = lq*16 + l15][r]:  key = nf*16 + lq*4 + r,  c = df*16 + l15
+        const int nf = key >> 4, lq = (key >> 2) & 3, r = key & 3, df = c >> 4, l15 = c & 15;
+        const float* p = part + ((int64_t)(b * H + h) * chunks) * 2 * NK * DV +
+                         (((nf * (DV / 16) + df) * 64 + lq * 16 + l15) << 2) + r;
+        float sk = 0.f, sv = 0.f;
+        for (int ch = 0; ch < chunks; ++ch) {
+            sk += p[(int64_t)ch * 2 * NK * DV];
+            sv += p[(int64_t)ch * 2 * NK * DV + NK * DV];
+        }
+        dK[i] = from_f32<T>(sk);
+        dV[i] = from_f32<T>(sv);
+    }
+}
+
+struct CtxPlan {
+    int ks, df, nkf;  // template selection
+    int chunks, rq;   // query rows per workgroup
+};
+
+bool plan_ctx(int B, int Tq, int Tk, int H, int d, bool backward, CtxPlan* pl) {
+    if (B < 1 || Tq < 1 || Tk < 1 || H < 1 || d < 8 || (d % 8) != 0 || d > 96 || Tk > 128) return false;
+    pl->ks = d <= 64 ? 2 : 3;
+    pl->df = (d + 15) / 16;
+    if (pl->df < 3) pl->df = 3;
+    pl->nkf = Tk <= 96 ? 6 : 8;
+    // enough workgroups to fill 256 CUs, but few chunks: every chunk re-stages K/V (and writes a partial in backward)
+    const int want = (backward ? 256 : 512) / (B * H);
+    int chunks = want < 1 ? 1 : want;
+    const int max_chunks = (Tq + 63) / 64;
+    if (chunks > max_chunks) chunks = max_chunks;
+    int rq = (Tq + chunks - 1) / chunks;
+    rq = (rq + 63) / 64 * 64;  // whole rounds of the four waves
+    pl->rq = rq;
+    pl->chunks = (Tq + rq - 1) / rq;
+    return true;
+}
+
+template <int KS, int DF, int NKF> constexpr int fwd_lds() {
+    using S = CtxShape<KS, DF, NKF>;
+    return (S::NK * S::KROW + S::DV * S::TROW) * 2;
+}
+template <int KS, int DF, int NKF> constexpr int bwd_lds() {
+    using S = CtxShape<KS, DF, NKF>;
+    constexpr int stage = (2 * S::NK * S::KROW + S::DV * S::TROW + 4 * 2 * 16 * S::KROW + 4 * 2 * 16 * S::TROW) * 2;
+    constexpr int red = 2 * S::NK * S::DV * 4;
+    return stage > red ? stage : red;
+}
+
+struct CtxArgs {
+    const void *Q, *K, *V, *dO;
+    void *O, *dQ, *dK, *dV;
+    float* part;
+    int B, Tq, Tk, H, d;
+    float scale;
+};
+
+template <typename T, int KS, int DF, int NKF>
+int launch_ctx(const CtxArgs& a, const CtxPlan& pl, bool backward, hipStream_t stream) {
+    const float l2e = a.scale * 1.4426950408889634f;
+    const dim3 grid((unsigned)(a.B * a.H * pl.chunks));
+    if (!backward) {
+        constexpr int lds = fwd_lds<KS, DF, NKF>();
+        auto kern = attn_ctx_fwd_kernel<T, KS, DF, NKF>;
+        if (lds > 48 * 1024) {
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (attr != hipSuccess) return LORA_E_LAUNCH;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, static_cast<const T*>(a.Q), static_cast<const T*>(a.K),
+                           static_cast<const T*>(a.V), static_cast<T*>(a.O), a.Tq, a.Tk, a.H, a.d, l2e, pl.rq, pl.chunks);
+        LORA_LAUNCH_CHECK();
+        return LORA_OK;
+    }
+    constexpr int lds = bwd_lds<KS, DF, NKF>();
+    auto kern = attn_ctx_bwd_kernel<T, KS, DF, NKF>;
+    if (lds > 48 * 1024) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (attr != hipSuccess) return LORA_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, static_cast<const T*>(a.Q), static_cast<const T*>(a.K),
+                       static_cast<const T*>(a.V), static_cast<const T*>(a.dO), static_cast<T*>(a.dQ), a.part, a.Tq,
+                       a.Tk, a.H, a.d, a.scale, l2e, pl.rq, pl.chunks);
+    LORA_LAUNCH_CHECK();
+    const int64_t total = (int64_t)a.B * a.Tk * a.H * a.d;
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    hipLaunchKernelGGL(attn_ctx_reduce_kernel<T>, dim3(blocks), dim3(256), 0, stream, a.part, static_cast<T*>(a.dK),
+                       static_cast<T*>(a.dV), a.B, a.Tk, a.H, a.d, pl.chunks, NKF * 16, DF * 16);
+    LORA_LAUNCH_CHECK();
+    return LORA_OK;
+}
+
+template <typename T>
+int dispatch_ctx(const CtxArgs& a, const CtxPlan& pl, bool backward, hipStream_t stream) {
+#define CTX_CASE(KS_, DF_, NKF_)                                   \
+    if (pl.ks == KS_ && pl.df == DF_ && pl.nkf == NKF_) return launch_ctx<T, KS_, DF_, NKF_>(a, pl, backward, stream);
+    CTX_CASE(2, 3, 6) CTX_CASE(2, 4, 6) CTX_CASE(3, 5, 6) CTX_CASE(3, 6, 6)
+    CTX_CASE(2, 3, 8) CTX_CASE(2, 4, 8) CTX_CASE(3, 5, 8) CTX_CASE(3, 6, 8)
+#undef CTX_CASE
+    return LORA_E_BADARG;
+}
+
+int run_ctx(const CtxArgs& a, bool backward, int dtype, hipStream_t stream) {
+    CtxPlan pl;
+    if (!plan_ctx(a.B, a.Tq, a.Tk, a.H, a.d, backward, &pl)) return LORA_E_BADARG;
+    switch (dtype) {
+        case LORA_F16: return dispatch_ctx<half_t>(a, pl, backward, stream);
+        case LORA_BF16: return dispatch_ctx<bf16_t>(a, pl, backward, stream);
+        default: return LORA_E_BADARG;  // fp32 tensors stay on the caller's generic attention
+    }
+}
+
+}  // namespace
+
+extern "C" int attn_ctx_supported(int B, int Tq, int Tk, int H, int d, int dtype) {
+    CtxPlan pl;
+    return (dtype == LORA_F16 || dtype == LORA_BF16) && plan_ctx(B, Tq, Tk, H, d, false, &pl) ? 1 : 0;
+}
+
+extern "C" int64_t attn_ctx_bwd_workspace_bytes(int B, int Tq, int Tk, int H, int d) {
+    CtxPlan pl;
+    if (!plan_ctx(B, Tq, Tk, H, d, true, &pl)) return -1;
+    return (int64_t)B * H * pl.chunks * 2 * (pl.nkf * 16) * (pl.df * 16) * 4;
+}
+
+extern "C" int attn_ctx_fwd(const void* Q, const void* K, const void* V, void* O, int B, int Tq, int Tk, int H, int d,
+                            float scale, int dtype, void* stream) {
+    if (!Q || !K || !V || !O) return LORA_E_BADARG;
+    if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || !aligned16(O)) return LORA_E_BADARG;
+    CtxArgs a{};
+    a.Q = Q; a.K = K; a.V = V; a.O = O; a.B = B; a.Tq = Tq; a.Tk = Tk; a.H = H; a.d = d; a.scale = scale;
+    return run_ctx(a, false, dtype, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int attn_ctx_bwd(const void* Q, const void* K, const void* V, const void* dO, void* dQ, void* dK, void* dV,
+                            void* workspace, int B, int Tq, int Tk, int H, int d, float scale, int dtype,
+                            void* stream) {
+    if (!Q || !K || !V || !dO || !dQ || !dK || !dV || !workspace) return LORA_E_BADARG;
+    if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || !aligned16(dO) || !aligned16(dQ) || !aligned16(workspace))
+        return LORA_E_BADARG;
+    CtxArgs a{};
+    a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.dQ = dQ; a.dK = dK; a.dV = dV; a.part = static_cast<float*>(workspace);
+    a.B = B; a.Tq = Tq; a.Tk = Tk; a.H = H; a.d = d; a.scale = scale;
+    return run_ctx(a, true, dtype, static_cast<hipStream_t>(stream));
+}

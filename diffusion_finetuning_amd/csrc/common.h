@@ -46,7 +46,7 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 // ProfWork object; LORA_LAUNCH attaches start/stop events to the dispatch itself (hipExtLaunchKernelGGL), so
 // the recorded time is the kernel's own duration, not the gap between host-side event records.
 enum ProfKernel {
-    PK_GEMM_128x128 = 0, PK_GEMM_128x64, PK_GEMM_64x64, PK_SKINNY_128, PK_SKINNY_64,
+    PK_GEMM_128x128 = 0, PK_GEMM_256x128, PK_GEMM_64x64, PK_SKINNY_128, PK_SKINNY_64,
     PK_GRAD_R4, PK_GRAD_R8, PK_GRAD_R16, PK_MSE, PK_OTHER, PK_COUNT
 };
 static_assert(PK_COUNT == LORA_PROF_KINDS, "lora_hip.h LORA_PROF_KINDS out of date");

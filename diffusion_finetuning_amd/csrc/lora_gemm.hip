@@ -92,11 +92,10 @@ __device__ unsigned long long g_stamps[8192 * 16];
 #define STAMP_WALL(i)
 #endif
 
-// One stage of the ring / the single staging buffer: A rows, B rows, factor rows.  With counted waits (3 stages) every
-// wave must issue the same number of DMA loads per stage, so the 16 factor rows are replicated over one staging pass;
-// with the 2-stage ring every wait is vmcnt(0) and only the first two waves load the factor tile.
+// One stage of the ring / the single staging buffer: A rows, B rows, 16 factor rows.  Only the first two waves load the
+// factor rows, so they carry one more DMA per stage than the others: the counted waits are picked per wave.
 template <int BM, int BN, bool MAIN, int STG, int NW> constexpr int stage_bytes() {
-    return (BM + (MAIN ? BN : 0) + (STG == 2 ? kRP : NW * 8)) * kRowBytes;
+    return (BM + (MAIN ? BN : 0) + kRP) * kRowBytes;
 }
 template <int BM, int BN, typename T, bool MAIN, int STG, int NW> constexpr int gemm_lds_bytes() {
     constexpr int ring = (STG > 0 ? STG : 1) * stage_bytes<BM, BN, MAIN, STG, NW>();
@@ -118,7 +117,6 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
     constexpr int WN = NW / 2;         // column waves (row waves: 2)
     constexpr int WTN = BN / WN;       // wave tile width
     constexpr int RPP = NW * 8;        // tile rows covered by one staging pass
-    constexpr int FROWS = STG == 2 ? kRP : RPP;
     constexpr int VEC = ElemTraits<T>::kVec;
     constexpr int BK = kRowBytes / (int)sizeof(T);
     constexpr int MI = BM / 32;  // 16-row fragments per wave
@@ -317,7 +315,8 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
     if constexpr (PIPE) {
         // ---- LDS-DMA ring.  Lane (row, physical chunk c') fetches logical chunk c' ^ (row & 7): the DMA
         // writes lane-linearly, so the swizzle lives on the source address and on the fragment reads.
-        constexpr int L = PA + (MAIN ? PB : 0) + 1;  // DMA loads per lane per stage
+        constexpr int L = PA + (MAIN ? PB : 0);  // DMA loads per lane per stage (+1 on the two factor-loading waves)
+        static_assert(kStages <= 3, "the counted wait below allows one newer stage in flight");
         const int src_off = (ld_chunk ^ (ld_row & 7)) * VEC;
         const int wave_rows = wave * 8 * kRowBytes;
         auto issue = [&](int kt, int buf) {
@@ -329,7 +328,7 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
 #pragma unroll
                 for (int i = 0; i < PB; ++i) glds16(b_ptr[i] + k0, st + OFF_B + RPP * i * kRowBytes);
             }
-            if (FROWS == RPP || wave < 2) glds16(f_ptr + k0, st + OFF_F);
+            if (wave < 2) glds16(f_ptr + k0, st + OFF_F);
         };
         constexpr int DIST = kStages - 1;  // K-steps in flight ahead of the one being multiplied
         issue(0, 0);
@@ -339,7 +338,11 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
         for (int kt = 0; kt < nk; ++kt) {
             // stage kt has landed for this wave once only the loads of the stages issued after it are outstanding
             if (DIST > 1 && kt + 1 < nk) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+                if (wave < 2) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L + 1) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+                }
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
                 for (int i = 0; i < PB; ++i)
                     *reinterpret_cast<Chunk<T>*>(smem + OFF_B + lds_off(ld_row + RPP * i, ld_chunk)) = rb[i];
             }
-            *reinterpret_cast<Chunk<T>*>(smem + OFF_F + lds_off(ld_row, ld_chunk)) = rfc;
+            if (ld_row < kRP) *reinterpret_cast<Chunk<T>*>(smem + OFF_F + lds_off(ld_row, ld_chunk)) = rfc;
         };
         load_step(0);
         for (int kt = 0; kt < nk; ++kt) {
@@ -411,8 +414,8 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
     __syncthreads();
 
     if (p.P != nullptr && tn == 0) {
-        const int row = tid >> 1, half = tid & 1;
-        if (row < BM && m0 + row < p.M) {
+        const int half = tid & 1;
+        for (int row = tid >> 1; row < BM && m0 + row < p.M; row += NT / 2) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int j = half * 8 + e;
@@ -437,32 +440,36 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
             for (int ni = 0; ni < NI; ++ni)
                 qf[ni] = *reinterpret_cast<const Frag*>(
                     sQ + ((wn * WTN + ni * 16 + l15) * kRP + j0) * (int)sizeof(T));
-            f32x4 pimg[MI][WN][2];
+            constexpr int MG = MI < 4 ? MI : 4;  // row fragments whose P image is fetched together
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const int row = wm * (BM / 2) + mi * 16 + l15;
+            for (int mg = 0; mg < MI; mg += MG) {
+                f32x4 pimg[MG][WN][2];
 #pragma unroll
-                for (int w = 0; w < WN; ++w) {
-                    const f32x4* src = reinterpret_cast<const f32x4*>(&sP[(w * BM + row) * kSPS + j0]);
-                    pimg[mi][w][0] = src[0];
-                    pimg[mi][w][1] = src[1];
-                }
-            }
+                for (int i = 0; i < MG; ++i) {
+                    const int row = wm * (BM / 2) + (mg + i) * 16 + l15;
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                Frag pf;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float v = 0.f;
-#pragma unroll
-                    for (int w = 0; w < WN; ++w) v += pimg[mi][w][e >> 2][e & 3];
-                    v *= p.scale;
-                    const T hi = from_f32<T>(v);
-                    const T lo = from_f32<T>(v - to_f32<T>(hi));
-                    pf[e] = lq < 2 ? hi : lo;
+                    for (int w = 0; w < WN; ++w) {
+                        const f32x4* src = reinterpret_cast<const f32x4*>(&sP[(w * BM + row) * kSPS + j0]);
+                        pimg[i][w][0] = src[0];
+                        pimg[i][w][1] = src[1];
+                    }
                 }
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = Mfma<T>::run(qf[ni], pf, acc[mi][ni]);
+                for (int i = 0; i < MG; ++i) {
+                    Frag pf;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int w = 0; w < WN; ++w) v += pimg[i][w][e >> 2][e & 3];
+                        v *= p.scale;
+                        const T hi = from_f32<T>(v);
+                        const T lo = from_f32<T>(v - to_f32<T>(hi));
+                        pf[e] = lq < 2 ? hi : lo;
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) acc[mg + i][ni] = Mfma<T>::run(qf[ni], pf, acc[mg + i][ni]);
+                }
             }
         } else {
             const float* q = reinterpret_cast<const float*>(sQ);
@@ -636,7 +643,7 @@ int launch_tile(GemmParams p, hipStream_t stream) {
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (attr != hipSuccess) return LORA_E_LAUNCH;
     }
-    constexpr int prof_id = MAIN ? (BM == 128 && BN == 128 ? PK_GEMM_128x128 : (BM == 128 ? PK_GEMM_128x64 : PK_GEMM_64x64))
+    constexpr int prof_id = MAIN ? (BM == 256 ? PK_GEMM_256x128 : (BM == 128 ? PK_GEMM_128x128 : PK_GEMM_64x64))
                                  : (BM == 128 ? PK_SKINNY_128 : PK_SKINNY_64);
     LORA_LAUNCH(prof_id, kern, dim3(p.tiles_m * p.tiles_n), dim3(NW * 64), lds, stream, p);
     LORA_LAUNCH_CHECK();
@@ -656,7 +663,10 @@ int forced_tile() {  // tuning knob for tools/gemm_bench.py only
 //    is 25-35 % faster than the 3-stage ring at one workgroup per CU on every shape that fills the chip;
 //  * 128×128 once its grid has >= 128 tiles (and the last column tile is not mostly padding), else 64×64;
 //  * 64×64: 2 stages (3 workgroups per CU) when there are >= 512 tiles to overlap, 3 stages (deeper prefetch)
-//    for the small latency-bound grids.  128×64 never won and is not instantiated.
+//    for the small latency-bound grids.  128×64 never won and is not instantiated;
+//  * 256×128 (3-stage ring, one workgroup of 4 waves per CU, 128×64 wave tiles) is correct but 20-100 % slower than
+//    two independent 128×128 workgroups per CU on every hot-path shape: one wave per SIMD cannot hide its own LDS and
+//    barrier latency.  Not instantiated either (the template still supports it).
 template <typename T, bool MAIN>
 int launch_pipe(const GemmParams& p, hipStream_t stream) {
     if (!MAIN) return launch_tile<T, 64, 64, false, 3>(p, stream);

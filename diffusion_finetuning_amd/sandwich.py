@@ -1,5 +1,6 @@
-"""Autograd fronts of the two ops sandwiched by the hot path in a transformer block:
-the GEGLU gate and the head split/merge around the attention core.  HIP device only, like the rest of the path."""
+"""Autograd fronts of the ops sandwiched by the hot path in a transformer block: the GEGLU gate,
+the short-context (cross-) attention core, and the head split/merge around the long-context attention core.
+HIP device only, like the rest of the path."""
 import torch
 from torch.autograd.function import once_differentiable
 
@@ -65,3 +66,37 @@ def split_heads(x: torch.Tensor, heads: int, padded_dim: int) -> torch.Tensor:
 def merge_heads(x: torch.Tensor, head_dim: int) -> torch.Tensor:
     """[B, H, N, D] → [B, N, H·head_dim] (padding dropped)."""
     return _MergeHeadsFn.apply(x, head_dim)
+
+
+class _CtxAttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, heads, scale):
+        q, k, v = (t if t.is_contiguous() else t.contiguous() for t in (q, k, v))
+        ctx.save_for_backward(q, k, v)
+        ctx.heads, ctx.scale = heads, scale
+        return nat.attn_ctx_fwd(q, k, v, heads, scale)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        q, k, v = ctx.saved_tensors
+        dq, dk, dv = nat.attn_ctx_bwd(q, k, v, dout if dout.is_contiguous() else dout.contiguous(), ctx.heads,
+                                      ctx.scale)
+        return dq, dk, dv, None, None
+
+
+def ctx_attention_supported(q: torch.Tensor, k: torch.Tensor, heads: int) -> bool:
+    """True when `ctx_attention` handles these tensors (f16/bf16 on the HIP device, ≤ 128 keys, head dim ≤ 96)."""
+    if not q.is_cuda or q.dim() != 3 or k.dim() != 3 or q.shape[-1] % heads:
+        return False
+    return nat.attn_ctx_supported(q.shape[0], q.shape[1], k.shape[1], heads, q.shape[-1] // heads, q.dtype)
+
+
+def ctx_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float = None) -> torch.Tensor:
+    """softmax(q·kᵀ·scale)·v per head for a short key/value sequence.  q [B,Tq,H·d], k/v [B,Tk,H·d] → [B,Tq,H·d]:
+    the layouts the to_q/to_k/to_v linears produce and to_out consumes, no head split/merge."""
+    if not q.is_cuda:
+        raise RuntimeError("ctx_attention runs only on a HIP device; there is no CPU fallback")
+    if scale is None:
+        scale = (q.shape[-1] // heads) ** -0.5
+    return _CtxAttentionFn.apply(q, k, v, heads, float(scale))

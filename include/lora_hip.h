@@ -209,6 +209,24 @@ int attn_split_heads(const void* src, void* dst, int B, int N, int H, int d, int
 int attn_merge_heads(const void* src, void* dst, int B, int N, int H, int d, int D, int dtype, void* stream);
 
 /*
+ * Short-context attention core  O = softmax(Q·Kᵀ·scale)·V  per head, for at most 128 keys: the cross-attention
+ * (`attn2`) between the to_q/to_k/to_v and to_out LoRA linears (diffusers CrossAttention.forward, the
+ * caller of the layers wrapped by lora_diffusion/lora.py:137-183).  Tensors keep the layout those linears produce
+ * and consume — Q/O/dO/dQ [B, Tq, H·d], K/V/dK/dV [B, Tk, H·d] — so there are no head split/merge copies.
+ *   attn_ctx_supported          : 1 when (shape, dtype) runs here: f16/bf16, d % 8 == 0, d <= 96, Tk <= 128.
+ *   attn_ctx_fwd                : O.  Nothing else is saved: backward recomputes the single key tile.
+ *   attn_ctx_bwd_workspace_bytes: size of the fp32 partial-sum workspace for dK/dV (-1 when unsupported).
+ *   attn_ctx_bwd                : dQ, dK, dV from Q, K, V, dO.  Deterministic (ordered partial sums, no atomics).
+ * Unsupported shapes return LORA_E_BADARG; the caller keeps its generic attention for those.
+ */
+int attn_ctx_supported(int B, int Tq, int Tk, int H, int d, int dtype);
+int attn_ctx_fwd(const void* Q, const void* K, const void* V, void* O, int B, int Tq, int Tk, int H, int d,
+                 float scale, int dtype, void* stream);
+int64_t attn_ctx_bwd_workspace_bytes(int B, int Tq, int Tk, int H, int d);
+int attn_ctx_bwd(const void* Q, const void* K, const void* V, const void* dO, void* dQ, void* dK, void* dV,
+                 void* workspace, int B, int Tq, int Tk, int H, int d, float scale, int dtype, void* stream);
+
+/*
  * Launch profiler (measurement only; off by default).  When enabled, the hot-path kernels are launched
  * with start/stop events attached to the dispatch itself, so each record is that kernel's own duration on
  * the caller's stream, together with the ALGORITHMIC bytes and flops of the call (formulas: DESIGN.md §5).

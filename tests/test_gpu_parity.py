@@ -718,6 +718,110 @@ def test_sandwich_ops_geglu_and_head_layouts(relerr, dtype):
     assert torch.equal(xs.grad.cpu(), w[..., :d].transpose(1, 2).reshape(B, N, H * d))
 
 
+def _attention_reference(q, k, v, heads):
+    """softmax(QKᵀ/√d)V per head in float64 on [B, T, H·d] tensors (the math of diffusers CrossAttention's core)."""
+    B, Tq, HD = q.shape
+    d = HD // heads
+    qh, kh, vh = (t.double().view(B, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    p = torch.softmax(qh @ kh.transpose(-1, -2) * d ** -0.5, dim=-1)
+    return (p @ vh).transpose(1, 2).reshape(B, Tq, HD)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_ctx_attention_core_against_float64_reference(relerr, dtype):
+    """f-4 (second part): the short-context attention kernels (forward, dQ/dK/dV) on cross-attention shapes — the SD
+    ones (77 text tokens; heads of 40 and 80), ragged query counts, 1 … 128 keys, every head-dim bucket — against
+    float64 math on the same 16-bit inputs.  Tolerance: one output rounding of the dtype plus the 16-bit P·V operand."""
+    from diffusion_finetuning_amd.sandwich import ctx_attention, ctx_attention_supported
+
+    tol = 2e-3 if dtype == torch.float16 else 1.2e-2
+    g = torch.Generator().manual_seed(21)
+    shapes = [(2, 64, 77, 2, 40), (1, 100, 77, 3, 40), (2, 256, 77, 8, 80), (1, 50, 5, 1, 8), (2, 130, 96, 2, 64),
+              (1, 77, 128, 2, 96), (1, 16, 1, 1, 16), (1, 333, 100, 4, 48), (4, 1024, 77, 8, 80), (2, 4096, 77, 8, 40)]
+    for (B, Tq, Tk, H, d) in shapes:
+        q = torch.randn(B, Tq, H * d, generator=g).to(dtype)
+        k = torch.randn(B, Tk, H * d, generator=g).to(dtype)
+        v = torch.randn(B, Tk, H * d, generator=g).to(dtype)
+        go = torch.randn(B, Tq, H * d, generator=g).to(dtype)
+        qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
+        want = _attention_reference(qr, kr, vr, H)
+        want.backward(go.double())
+        qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+        assert ctx_attention_supported(qd, kd, H)
+        got = ctx_attention(qd, kd, vd, H)
+        got.backward(go.to(DEV))
+        for name, a, b in (("o", got, want), ("dq", qd.grad, qr.grad), ("dk", kd.grad, kr.grad), ("dv", vd.grad, vr.grad)):
+            assert relerr(a, b) < tol, (name, (B, Tq, Tk, H, d), relerr(a, b))
+
+
+def test_ctx_attention_is_deterministic_and_rejects_what_it_does_not_cover():
+    from diffusion_finetuning_amd.sandwich import ctx_attention, ctx_attention_supported
+
+    g = torch.Generator().manual_seed(22)
+    q = torch.randn(2, 4096, 320, generator=g).half().to(DEV).requires_grad_(True)
+    k = torch.randn(2, 77, 320, generator=g).half().to(DEV).requires_grad_(True)
+    v = torch.randn(2, 77, 320, generator=g).half().to(DEV).requires_grad_(True)
+    go = torch.randn(2, 4096, 320, generator=g).half().to(DEV)
+    runs = []
+    for _ in range(2):
+        o = ctx_attention(q, k, v, 8)
+        runs.append((o.detach().clone(),) + tuple(t.clone() for t in torch.autograd.grad(o, (q, k, v), go)))
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)  # ordered partial sums: bit-identical dK/dV from run to run
+    # outside the kernel's envelope the caller must keep its generic attention: fp32, long contexts, wide heads
+    assert not ctx_attention_supported(q.float(), k.float(), 8)
+    assert not ctx_attention_supported(q, torch.zeros(2, 129, 320, device=DEV, dtype=torch.float16), 8)
+    assert not ctx_attention_supported(q, k, 2)  # head dim 160
+    with pytest.raises(RuntimeError):
+        nat.attn_ctx_fwd(q.detach().float(), k.detach().float(), v.detach().float(), 8, 0.1)
+
+
+def test_harness_cross_attention_uses_the_hip_core_and_matches_stock(relerr):
+    """The harness transformer block routes its cross-attention through ctx_attention; the block's output and the
+    LoRA gradients agree with the same block run through stock SDPA."""
+    import harness.unet as hu
+    from diffusion_finetuning_amd import sandwich
+
+    torch.manual_seed(5)
+    blk = hu.BasicTransformerBlock(320, 8, 40, 768).to(DEV).half()
+    blk.requires_grad_(False)
+    params, _ = dfa.inject_trainable_lora(blk, r=4)
+    plist = list(itertools.chain(*params))
+    with torch.no_grad():
+        for i, p in enumerate(plist):
+            if i % 2 == 1:
+                p.copy_(torch.randn_like(p) * 0.02)
+    x = torch.randn(2, 256, 320, device=DEV).half()
+    ctx = torch.randn(2, 77, 768, device=DEV).half()
+    calls = []
+    real = sandwich.ctx_attention
+
+    def spy(*a, **kw):
+        calls.append(1)
+        return real(*a, **kw)
+
+    sandwich.ctx_attention = spy
+    try:
+        out = blk(x, ctx)
+        out.float().pow(2).sum().mul(1e-2).backward()
+    finally:
+        sandwich.ctx_attention = real
+    assert len(calls) == 1  # attn2 only: attn1 has 256 keys
+    grads = [p.grad.clone() for p in plist]
+    for p in plist:
+        p.grad = None
+    supported = sandwich.ctx_attention_supported
+    sandwich.ctx_attention_supported = lambda *a, **kw: False
+    try:
+        ref = blk(x, ctx)
+        ref.float().pow(2).sum().mul(1e-2).backward()
+    finally:
+        sandwich.ctx_attention_supported = supported
+    assert relerr(out, ref) < 2e-3
+    for a, p in zip(grads, plist):
+        assert relerr(a, p.grad) < 2e-2
+
+
 def test_drop_in_under_ddp_autocast_and_checkpointing(golden_trajectory, tiny_unet_factory, relerr):
     """What `accelerate` does around the reference trainer (train_lora_dreambooth.py:489-494,627-630,744-757): the
     model wrapped in torch DistributedDataParallel (1-rank RCCL group), fp16 autocast with a GradScaler, and
