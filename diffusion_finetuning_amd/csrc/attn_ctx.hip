@@ -104,12 +104,13 @@ template <typename T, int KS, int DF, int NKF> struct StageRegs {
         }
     }
     // transposed [DV][TROW] with the keys permuted (operand rows = head dim, contraction over keys)
-    __device__ __forceinline__ void store_transposed(T* dst) const {
+    // (only the head-dim columns c0 .. c0 + DV - 1: the slice this workgroup produces)
+    __device__ __forceinline__ void store_transposed(T* dst, int c0) const {
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             const int idx = threadIdx.x + i * 256;
-            const int key = idx / CPR, c = (idx - key * CPR) * 8;
-            if (idx < N && c < S::DV) {
+            const int key = idx / CPR, c = (idx - key * CPR) * 8 - c0;
+            if (idx < N && c >= 0 && c < S::DV) {
                 const int pos = key_pos(key);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) dst[(c + e) * S::TROW + pos] = v[i].v[e];
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256) void attn_ctx_fwd_kernel(const T* __restrict__
         kr.load(K + (int64_t)b * Tk * HD + h * d, HD, Tk, d);
         vr.load(V + (int64_t)b * Tk * HD + h * d, HD, Tk, d);
         kr.store_rows(Ks);
-        vr.store_transposed(Vt);
+        vr.store_transposed(Vt, 0);
     }
     __syncthreads();
 
@@ -260,11 +261,11 @@ __global__ __launch_bounds__(256) void attn_ctx_fwd_kernel(const T* __restrict__
 // transposed fragments for the contraction over the 16 query rows: lane = (head-dim column l15, rows lq*4 .. +3),
 // read from the wave's own LDS copy of the block's rows ([16][KROW], zero beyond the valid rows and d)
 template <typename T, int DF, int KROW>
-__device__ __forceinline__ void load_col_frags(const T* tile, int l15, int lq, T (&f)[DF][4]) {
+__device__ __forceinline__ void load_col_frags(const T* tile, int c0, int l15, int lq, T (&f)[DF][4]) {
 #pragma unroll
     for (int df = 0; df < DF; ++df)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) f[df][e] = tile[(lq * 4 + e) * KROW + df * 16 + l15];
+        for (int e = 0; e < 4; ++e) f[df][e] = tile[(lq * 4 + e) * KROW + c0 + df * 16 + l15];
 }
 
 template <typename T, int KS, int DF, int NKF>
@@ -291,13 +292,14 @@ __global__ __launch_bounds__(256) void attn_ctx_bwd_kernel(const T* __restrict__
     const int64_t HD = (int64_t)H * d;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
+    const int c0 = blockIdx.y * S::DV;  // head-dim slice whose dQ / dK / dV this workgroup produces
 
     {
         StageRegs<T, KS, DF, NKF> kr, vr;
         kr.load(K + (int64_t)b * Tk * HD + h * d, HD, Tk, d);
         vr.load(V + (int64_t)b * Tk * HD + h * d, HD, Tk, d);
         kr.store_rows(Ks);
-        kr.store_transposed(Kt);
+        kr.store_transposed(Kt, c0);
         vr.store_rows(Vs);
     }
     __syncthreads();
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(256) void attn_ctx_bwd_kernel(const T* __restrict__
                     const F8 kf = *reinterpret_cast<const F8*>(Kt + (df * 16 + l15) * S::TROW + kk * 32 + lq * 8);
                     g = Mma<T>::k32(kf, dsf[kk], g);
                 }
-                const int c = df * 16 + lq * 4;
+                const int c = c0 + df * 16 + lq * 4;
                 if (valid && c < d) {
                     Quad4<T> out;
 #pragma unroll
@@ -388,8 +390,8 @@ __global__ __launch_bounds__(256) void attn_ctx_bwd_kernel(const T* __restrict__
         // ---- dK, dV: contraction over the 16 query rows.  Operands with the keys (resp. head-dim columns) along the
         // lanes and 4 query rows per lane, read back transposed from the wave's LDS tiles --------------------------
         T qT[DF][4], gT[DF][4];
-        load_col_frags<T, DF, S::KROW>(Qw, l15, lq, qT);
-        load_col_frags<T, DF, S::KROW>(Gw, l15, lq, gT);
+        load_col_frags<T, DF, S::KROW>(Qw, c0, l15, lq, qT);
+        load_col_frags<T, DF, S::KROW>(Gw, c0, l15, lq, gT);
 #pragma unroll
         for (int nf = 0; nf < NKF; ++nf) {
             const int pos = (nf >> 1) * 32 + ((l15 >> 2) << 3) + (nf & 1) * 4 + (l15 & 3);  // key_pos(nf*16 + l15)
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(256) void attn_ctx_bwd_kernel(const T* __restrict__
         }
         __syncthreads();
     }
-    float* out = part + (int64_t)blockIdx.x * 2 * S::NK * S::DV;
+    float* out = part + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 2 * S::NK * S::DV;
     for (int idx = threadIdx.x * 4; idx < 2 * S::NK * S::DV; idx += 1024)
         *reinterpret_cast<f32x4*>(out + idx) = *reinterpret_cast<const f32x4*>(red + idx);
 }
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(256) void attn_ctx_bwd_kernel(const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void attn_ctx_reduce_kernel(const float* __restrict__ part, T* __restrict__ dK,
                                                                T* __restrict__ dV, int B, int Tk, int H, int d,
-                                                               int chunks, int NK, int DV) {
+                                                               int chunks, int slices, int NK, int DV) {
     const int64_t total = (int64_t)B * Tk * H * d;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % d);
@@ -463,13 +465,14 @@ __global__ __launch_bounds__(256) void attn_ctx_reduce_kernel(const float* __res
         const int key = (int)((i / ((int64_t)d * H)) % Tk);
         const int b = (int)(i / ((int64_t)d * H * Tk));
         // fragment order [nf][df][lane = lq*16 + l15][r]:  key = nf*16 + lq*4 + r,  c = df*16 + l15
-        const int nf = key >> 4, lq = (key >> 2) & 3, r = key & 3, df = c >> 4, l15 = c & 15;
-        const float* p = part + ((int64_t)(b * H + h) * chunks) * 2 * NK * DV +
+        const int sl = c / DV, cs = c - sl * DV;  // head-dim slice and column inside it
+        const int nf = key >> 4, lq = (key >> 2) & 3, r = key & 3, df = cs >> 4, l15 = cs & 15;
+        const float* p = part + (((int64_t)(b * H + h) * chunks) * slices + sl) * 2 * NK * DV +
                          (((nf * (DV / 16) + df) * 64 + lq * 16 + l15) << 2) + r;
         float sk = 0.f, sv = 0.f;
         for (int ch = 0; ch < chunks; ++ch) {
-            sk += p[(int64_t)ch * 2 * NK * DV];
-            sv += p[(int64_t)ch * 2 * NK * DV + NK * DV];
+            sk += p[(int64_t)ch * slices * 2 * NK * DV];
+            sv += p[(int64_t)ch * slices * 2 * NK * DV + NK * DV];
         }
         dK[i] = from_f32<T>(sk);
         dV[i] = from_f32<T>(sv);
@@ -477,18 +480,27 @@ __global__ __launch_bounds__(256) void attn_ctx_reduce_kernel(const float* __res
 }
 
 struct CtxPlan {
-    int ks, df, nkf;  // template selection
+    int ks, df, nkf;  // template selection (df: fragments per workgroup — the whole head forward, one slice backward)
+    int slices;       // head-dim slices in backward (dK/dV accumulators of a whole wide head do not fit in registers)
     int chunks, rq;   // query rows per workgroup
 };
 
 bool plan_ctx(int B, int Tq, int Tk, int H, int d, bool backward, CtxPlan* pl) {
-    if (B < 1 || Tq < 1 || Tk < 1 || H < 1 || d < 8 || (d % 8) != 0 || d > 96 || Tk > 128) return false;
-    pl->ks = d <= 64 ? 2 : 3;
-    pl->df = (d + 15) / 16;
-    if (pl->df < 3) pl->df = 3;
+    if (B < 1 || Tq < 1 || Tk < 1 || H < 1 || d < 8 || (d % 8) != 0 || d > 160 || Tk > 128) return false;
+    if (d > 96 && Tk > 96) return false;  // the wide-head backward with 128 keys does not fit in LDS
+    pl->slices = 1;
+    if (d <= 96) {
+        pl->ks = d <= 64 ? 2 : 3;
+        pl->df = (d + 15) / 16;
+        if (pl->df < 3) pl->df = 3;
+    } else {
+        pl->ks = 5;
+        pl->df = backward ? 5 : 10;
+        pl->slices = backward ? 2 : 1;
+    }
     pl->nkf = Tk <= 96 ? 6 : 8;
     // enough workgroups to fill 256 CUs, but few chunks: every chunk re-stages K/V (and writes a partial in backward)
-    const int want = (backward ? 256 : 512) / (B * H);
+    const int want = (backward ? 256 : 512) / (B * H * pl->slices);
     int chunks = want < 1 ? 1 : want;
     const int max_chunks = (Tq + 63) / 64;
     if (chunks > max_chunks) chunks = max_chunks;
@@ -518,11 +530,11 @@ struct CtxArgs {
     float scale;
 };
 
-template <typename T, int KS, int DF, int NKF>
-int launch_ctx(const CtxArgs& a, const CtxPlan& pl, bool backward, hipStream_t stream) {
+template <typename T, int KS, int DF, int NKF, bool BWD>
+int launch_ctx(const CtxArgs& a, const CtxPlan& pl, hipStream_t stream) {
     const float l2e = a.scale * 1.4426950408889634f;
     const dim3 grid((unsigned)(a.B * a.H * pl.chunks));
-    if (!backward) {
+    if constexpr (!BWD) {
         constexpr int lds = fwd_lds<KS, DF, NKF>();
         auto kern = attn_ctx_fwd_kernel<T, KS, DF, NKF>;
         if (lds > 48 * 1024) {
@@ -534,7 +546,7 @@ int launch_ctx(const CtxArgs& a, const CtxPlan& pl, bool backward, hipStream_t s
                            static_cast<const T*>(a.V), static_cast<T*>(a.O), a.Tq, a.Tk, a.H, a.d, l2e, pl.rq, pl.chunks);
         LORA_LAUNCH_CHECK();
         return LORA_OK;
-    }
+    } else {
     constexpr int lds = bwd_lds<KS, DF, NKF>();
     auto kern = attn_ctx_bwd_kernel<T, KS, DF, NKF>;
     if (lds > 48 * 1024) {
@@ -542,25 +554,35 @@ int launch_ctx(const CtxArgs& a, const CtxPlan& pl, bool backward, hipStream_t s
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (attr != hipSuccess) return LORA_E_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, static_cast<const T*>(a.Q), static_cast<const T*>(a.K),
-                       static_cast<const T*>(a.V), static_cast<const T*>(a.dO), static_cast<T*>(a.dQ), a.part, a.Tq,
+    hipLaunchKernelGGL(kern, dim3(grid.x, (unsigned)pl.slices), dim3(256), lds, stream, static_cast<const T*>(a.Q),
+                       static_cast<const T*>(a.K), static_cast<const T*>(a.V), static_cast<const T*>(a.dO),
+                       static_cast<T*>(a.dQ), a.part, a.Tq,
                        a.Tk, a.H, a.d, a.scale, l2e, pl.rq, pl.chunks);
     LORA_LAUNCH_CHECK();
     const int64_t total = (int64_t)a.B * a.Tk * a.H * a.d;
     const unsigned blocks = (unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
     hipLaunchKernelGGL(attn_ctx_reduce_kernel<T>, dim3(blocks), dim3(256), 0, stream, a.part, static_cast<T*>(a.dK),
-                       static_cast<T*>(a.dV), a.B, a.Tk, a.H, a.d, pl.chunks, NKF * 16, DF * 16);
+                       static_cast<T*>(a.dV), a.B, a.Tk, a.H, a.d, pl.chunks, pl.slices, NKF * 16, DF * 16);
     LORA_LAUNCH_CHECK();
     return LORA_OK;
+    }
 }
 
 template <typename T>
 int dispatch_ctx(const CtxArgs& a, const CtxPlan& pl, bool backward, hipStream_t stream) {
-#define CTX_CASE(KS_, DF_, NKF_)                                   \
-    if (pl.ks == KS_ && pl.df == DF_ && pl.nkf == NKF_) return launch_ctx<T, KS_, DF_, NKF_>(a, pl, backward, stream);
+#define CTX_CASE(KS_, DF_, NKF_)                                                                 \
+    if (pl.ks == KS_ && pl.df == DF_ && pl.nkf == NKF_)                                              \
+        return backward ? launch_ctx<T, KS_, DF_, NKF_, true>(a, pl, stream) : launch_ctx<T, KS_, DF_, NKF_, false>(a, pl, stream);
+#define CTX_FWD_ONLY(KS_, DF_, NKF_) \
+    if (!backward && pl.ks == KS_ && pl.df == DF_ && pl.nkf == NKF_) return launch_ctx<T, KS_, DF_, NKF_, false>(a, pl, stream);
+#define CTX_BWD_ONLY(KS_, DF_, NKF_) \
+    if (backward && pl.ks == KS_ && pl.df == DF_ && pl.nkf == NKF_) return launch_ctx<T, KS_, DF_, NKF_, true>(a, pl, stream);
     CTX_CASE(2, 3, 6) CTX_CASE(2, 4, 6) CTX_CASE(3, 5, 6) CTX_CASE(3, 6, 6)
     CTX_CASE(2, 3, 8) CTX_CASE(2, 4, 8) CTX_CASE(3, 5, 8) CTX_CASE(3, 6, 8)
+    CTX_FWD_ONLY(5, 10, 6) CTX_BWD_ONLY(5, 5, 6)  // heads of 104 … 160 (SD: 160 at the two coarsest levels)
 #undef CTX_CASE
+#undef CTX_FWD_ONLY
+#undef CTX_BWD_ONLY
     return LORA_E_BADARG;
 }
 
@@ -584,7 +606,7 @@ extern "C" int attn_ctx_supported(int B, int Tq, int Tk, int H, int d, int dtype
 extern "C" int64_t attn_ctx_bwd_workspace_bytes(int B, int Tq, int Tk, int H, int d) {
     CtxPlan pl;
     if (!plan_ctx(B, Tq, Tk, H, d, true, &pl)) return -1;
-    return (int64_t)B * H * pl.chunks * 2 * (pl.nkf * 16) * (pl.df * 16) * 4;
+    return (int64_t)B * H * pl.chunks * pl.slices * 2 * (pl.nkf * 16) * (pl.df * 16) * 4;
 }
 
 extern "C" int attn_ctx_fwd(const void* Q, const void* K, const void* V, void* O, int B, int Tq, int Tk, int H, int d,

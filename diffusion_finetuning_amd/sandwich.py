@@ -86,7 +86,7 @@ class _CtxAttentionFn(torch.autograd.Function):
 
 
 def ctx_attention_supported(q: torch.Tensor, k: torch.Tensor, heads: int) -> bool:
-    """True when `ctx_attention` handles these tensors (f16/bf16 on the HIP device, ≤ 128 keys, head dim ≤ 96)."""
+    """True when `ctx_attention` handles these tensors (f16/bf16 on the HIP device, ≤ 128 keys, head dim ≤ 160)."""
     if not q.is_cuda or q.dim() != 3 or k.dim() != 3 or q.shape[-1] % heads:
         return False
     return nat.attn_ctx_supported(q.shape[0], q.shape[1], k.shape[1], heads, q.shape[-1] // heads, q.dtype)

@@ -123,7 +123,7 @@ def _attention_core(q, k, v, heads):
     memory-efficient backend).  Zero columns add nothing to QKᵀ and produce zero output columns, which are dropped
     again; the scale stays 1/√d of the true head size.  The [B,N,H·d] ↔ [B,H,N,D] re-layouts (with the padding)
     are single streaming kernels (diffusion_finetuning_amd.sandwich) instead of generic strided copies.
-    Cross-attention (≤ 128 keys, head dim ≤ 96, 16-bit) skips all of that: csrc/attn_ctx.hip works on the
+    Cross-attention (≤ 128 keys, head dim ≤ 160, 16-bit) skips all of that: csrc/attn_ctx.hip works on the
     [B,N,H·d] tensors directly."""
     b, n, hd = q.shape
     d = hd // heads

@@ -213,7 +213,7 @@ int attn_merge_heads(const void* src, void* dst, int B, int N, int H, int d, int
  * (`attn2`) between the to_q/to_k/to_v and to_out LoRA linears (diffusers CrossAttention.forward, the
  * caller of the layers wrapped by lora_diffusion/lora.py:137-183).  Tensors keep the layout those linears produce
  * and consume — Q/O/dO/dQ [B, Tq, H·d], K/V/dK/dV [B, Tk, H·d] — so there are no head split/merge copies.
- *   attn_ctx_supported          : 1 when (shape, dtype) runs here: f16/bf16, d % 8 == 0, d <= 96, Tk <= 128.
+ *   attn_ctx_supported          : 1 when (shape, dtype) runs here: f16/bf16, d % 8 == 0, d <= 160, Tk <= 128 (<= 96 when d > 96).
  *   attn_ctx_fwd                : O.  Nothing else is saved: backward recomputes the single key tile.
  *   attn_ctx_bwd_workspace_bytes: size of the fp32 partial-sum workspace for dK/dV (-1 when unsupported).
  *   attn_ctx_bwd                : dQ, dK, dV from Q, K, V, dO.  Deterministic (ordered partial sums, no atomics).

@@ -737,7 +737,8 @@ def test_ctx_attention_core_against_float64_reference(relerr, dtype):
     tol = 2e-3 if dtype == torch.float16 else 1.2e-2
     g = torch.Generator().manual_seed(21)
     shapes = [(2, 64, 77, 2, 40), (1, 100, 77, 3, 40), (2, 256, 77, 8, 80), (1, 50, 5, 1, 8), (2, 130, 96, 2, 64),
-              (1, 77, 128, 2, 96), (1, 16, 1, 1, 16), (1, 333, 100, 4, 48), (4, 1024, 77, 8, 80), (2, 4096, 77, 8, 40)]
+              (1, 77, 128, 2, 96), (1, 16, 1, 1, 16), (1, 333, 100, 4, 48), (4, 1024, 77, 8, 80), (2, 4096, 77, 8, 40),
+              (4, 256, 77, 8, 160), (2, 64, 77, 8, 160), (1, 70, 90, 2, 104)]
     for (B, Tq, Tk, H, d) in shapes:
         q = torch.randn(B, Tq, H * d, generator=g).to(dtype)
         k = torch.randn(B, Tk, H * d, generator=g).to(dtype)
@@ -771,7 +772,7 @@ def test_ctx_attention_is_deterministic_and_rejects_what_it_does_not_cover():
     # outside the kernel's envelope the caller must keep its generic attention: fp32, long contexts, wide heads
     assert not ctx_attention_supported(q.float(), k.float(), 8)
     assert not ctx_attention_supported(q, torch.zeros(2, 129, 320, device=DEV, dtype=torch.float16), 8)
-    assert not ctx_attention_supported(q, k, 2)  # head dim 160
+    assert not ctx_attention_supported(q, k, 1)  # head dim 320
     with pytest.raises(RuntimeError):
         nat.attn_ctx_fwd(q.detach().float(), k.detach().float(), v.detach().float(), 8, 0.1)
 

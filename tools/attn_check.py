@@ -66,9 +66,10 @@ def timing(B, Tq, Tk, H, d):
 ok = True
 for dtype in (torch.float16, torch.bfloat16):
     for (B, Tq, Tk, H, d) in [(2, 64, 77, 2, 40), (1, 100, 77, 3, 40), (2, 256, 77, 8, 80), (1, 50, 5, 1, 8), (2, 130, 96, 2, 64),
-                              (1, 77, 128, 2, 96), (1, 16, 1, 1, 16), (4, 1024, 77, 8, 80), (4, 4096, 77, 8, 40), (1, 333, 100, 4, 48)]:
+                              (1, 77, 128, 2, 96), (1, 16, 1, 1, 16), (4, 1024, 77, 8, 80), (4, 4096, 77, 8, 40), (1, 333, 100, 4, 48),
+                              (4, 256, 77, 8, 160), (2, 64, 77, 8, 160), (1, 70, 90, 2, 104)]:
         ok &= check(B, Tq, Tk, H, d, dtype)
 print("ALL OK" if ok else "SOME FAILED")
 if "--time" in sys.argv:
-    for shp in [(4, 4096, 77, 8, 40), (4, 1024, 77, 8, 80)]:
+    for shp in [(4, 4096, 77, 8, 40), (4, 1024, 77, 8, 80), (4, 256, 77, 8, 160)]:
         timing(*shp)
