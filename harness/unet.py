@@ -137,7 +137,9 @@ def _attention_core(q, k, v, heads):
         return ctx_attention(q, k, v, heads)
     D = 64 if d < 64 else (128 if d < 128 else d)
     q4, k4, v4 = split_heads(q, heads, D), split_heads(k, heads, D), split_heads(v, heads, D)
-    with sdpa_kernel([SDPBackend.EFFICIENT_ATTENTION, SDPBackend.FLASH_ATTENTION, SDPBackend.MATH]):
+    # set_priority: without it the list only ENABLES backends and PyTorch still tries flash first, whose backward is
+    # 1.65x slower than the memory-efficient one at these shapes (1454 vs 880 us fwd+bwd, 4x8 heads, 4096 tokens)
+    with sdpa_kernel([SDPBackend.EFFICIENT_ATTENTION, SDPBackend.FLASH_ATTENTION, SDPBackend.MATH], set_priority=True):
         o = F.scaled_dot_product_attention(q4, k4, v4, scale=d ** -0.5)
     return merge_heads(o, d)
 
