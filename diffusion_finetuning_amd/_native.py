@@ -55,6 +55,7 @@ SIGNATURES = {
     "geglu_gate_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "attn_split_heads": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "attn_merge_heads": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "attn_merge_heads_strided": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp]),
     "attn_ctx_supported": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "attn_ctx_fwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "attn_ctx_bwd_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
@@ -364,12 +365,18 @@ def attn_split_heads(x3, heads: int, D: int):
 
 
 def attn_merge_heads(x4, d: int):
-    """x4 [B, H, N, D] contiguous → [B, N, H·d]."""
+    """x4 [B, H, N, D] → [B, N, H·d].  x4 may be a strided view with a contiguous last dim (what the attention core
+    returns); anything else is made contiguous first."""
     _require_device(x4)
     B, H, N, D = x4.shape
+    vec = 16 // x4.element_size()
+    sB, sH, sN, sD = x4.stride()
+    if sD != 1 or sB % vec or sH % vec or sN % vec or x4.data_ptr() % 16:
+        x4 = x4.contiguous()
+        sB, sH, sN, sD = x4.stride()
     out = torch.empty((B, N, H * d), dtype=x4.dtype, device=x4.device)
-    _check(lib().attn_merge_heads(_ptr(x4), _ptr(out), B, N, H, d, D, dtype_code(x4.dtype), _stream(x4)),
-           "attn_merge_heads")
+    _check(lib().attn_merge_heads_strided(_ptr(x4), _ptr(out), B, N, H, d, D, sB, sH, sN, dtype_code(x4.dtype),
+                                          _stream(x4)), "attn_merge_heads_strided")
     return out
 
 

@@ -58,18 +58,23 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const T* y, const T* dou
 
 // split: src [B, N, H·d] → dst [B, H, N, D] (columns d..D-1 zero);  merge: src [B, H, N, D] → dst [B, N, H·d]
 template <typename T, bool SPLIT>
-__global__ __launch_bounds__(256) void heads_kernel(const T* src, T* dst, int B, int N, int H, int d, int D) {
+__global__ __launch_bounds__(256) void heads_kernel(const T* src, T* dst, int B, int N, int H, int d, int D,
+                                                    int64_t sB, int64_t sH, int64_t sN) {  // strides of the 4-D side
     constexpr int VEC = ElemTraits<T>::kVec;
     const int cpd = D / VEC;  // chunks per padded head row
     const int64_t total = (int64_t)B * H * N * cpd;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int ch = (int)(i % cpd);
-        const int64_t row = i / cpd;          // (b, h, n) of the [B,H,N,D] side
-        const int n = (int)(row % N);
-        const int h = (int)((row / N) % H);
+        const int64_t row = i / cpd;
+        // walk the rows in the order in which the 4-D side lies in memory: (b,h,n) for a contiguous [B,H,N,D] tensor,
+        // (b,n,h) for a transposed view of [B,N,H,D] — then both sides are streamed linearly
+        const bool n_major = sH < sN;
+        const int n = (int)(n_major ? (row / H) % N : row % N);
+        const int h = (int)(n_major ? row % H : (row / N) % H);
         const int64_t b = row / ((int64_t)N * H);
         const int col = ch * VEC;
         const int64_t flat = ((b * N + n) * H + h) * d + col;  // [B,N,H·d] side
+        const int64_t off4 = b * sB + h * sH + n * sN + col;   // [B,H,N,D] side (rows may be strided)
         if (SPLIT) {
             Chunk<T> v;
             if (col < d) {
@@ -78,9 +83,9 @@ __global__ __launch_bounds__(256) void heads_kernel(const T* src, T* dst, int B,
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) v.v[e] = from_f32<T>(0.f);
             }
-            *reinterpret_cast<Chunk<T>*>(dst + row * D + col) = v;
+            *reinterpret_cast<Chunk<T>*>(dst + off4) = v;
         } else if (col < d) {
-            *reinterpret_cast<Chunk<T>*>(dst + flat) = *reinterpret_cast<const Chunk<T>*>(src + row * D + col);
+            *reinterpret_cast<Chunk<T>*>(dst + flat) = *reinterpret_cast<const Chunk<T>*>(src + off4);
         }
     }
 }
@@ -103,18 +108,19 @@ int launch_geglu(const void* y, const void* dout, void* out, int64_t M, int C, b
 }
 
 template <typename T>
-int launch_heads(const void* src, void* dst, int B, int N, int H, int d, int D, bool split, hipStream_t s) {
+int launch_heads(const void* src, void* dst, int B, int N, int H, int d, int D, int64_t sB, int64_t sH, int64_t sN,
+                 bool split, hipStream_t s) {
     constexpr int VEC = ElemTraits<T>::kVec;
-    if (d % VEC || D % VEC || D < d) return LORA_E_UNSUPPORTED;
+    if (d % VEC || D % VEC || D < d || sB % VEC || sH % VEC || sN % VEC) return LORA_E_UNSUPPORTED;
     int64_t blocks = ((int64_t)B * H * N * (D / VEC) + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
     if (split)
         hipLaunchKernelGGL((heads_kernel<T, true>), dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const T*>(src),
-                           static_cast<T*>(dst), B, N, H, d, D);
+                           static_cast<T*>(dst), B, N, H, d, D, sB, sH, sN);
     else
         hipLaunchKernelGGL((heads_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const T*>(src),
-                           static_cast<T*>(dst), B, N, H, d, D);
+                           static_cast<T*>(dst), B, N, H, d, D, sB, sH, sN);
     LORA_LAUNCH_CHECK();
     return LORA_OK;
 }
@@ -147,28 +153,33 @@ extern "C" int geglu_gate_bwd(const void* y, const void* dout, void* dy, int64_t
     }
 }
 
-extern "C" int attn_split_heads(const void* src, void* dst, int B, int N, int H, int d, int D, int dtype,
-                                void* stream) {
+namespace {
+int run_heads(const void* src, void* dst, int B, int N, int H, int d, int D, int64_t sB, int64_t sH, int64_t sN,
+              bool split, int dtype, void* stream) {
     if (!src || !dst || B < 1 || N < 1 || H < 1 || d < 1) return LORA_E_BADARG;
     if (!aligned16(src) || !aligned16(dst)) return LORA_E_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (dtype) {
-        case LORA_F32: return launch_heads<float>(src, dst, B, N, H, d, D, true, s);
-        case LORA_F16: return launch_heads<half_t>(src, dst, B, N, H, d, D, true, s);
-        case LORA_BF16: return launch_heads<bf16_t>(src, dst, B, N, H, d, D, true, s);
+        case LORA_F32: return launch_heads<float>(src, dst, B, N, H, d, D, sB, sH, sN, split, s);
+        case LORA_F16: return launch_heads<half_t>(src, dst, B, N, H, d, D, sB, sH, sN, split, s);
+        case LORA_BF16: return launch_heads<bf16_t>(src, dst, B, N, H, d, D, sB, sH, sN, split, s);
         default: return LORA_E_BADARG;
     }
+}
+}  // namespace
+
+extern "C" int attn_split_heads(const void* src, void* dst, int B, int N, int H, int d, int D, int dtype,
+                                void* stream) {
+    return run_heads(src, dst, B, N, H, d, D, (int64_t)H * N * D, (int64_t)N * D, D, true, dtype, stream);
 }
 
 extern "C" int attn_merge_heads(const void* src, void* dst, int B, int N, int H, int d, int D, int dtype,
                                 void* stream) {
-    if (!src || !dst || B < 1 || N < 1 || H < 1 || d < 1) return LORA_E_BADARG;
-    if (!aligned16(src) || !aligned16(dst)) return LORA_E_ALIGN;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    switch (dtype) {
-        case LORA_F32: return launch_heads<float>(src, dst, B, N, H, d, D, false, s);
-        case LORA_F16: return launch_heads<half_t>(src, dst, B, N, H, d, D, false, s);
-        case LORA_BF16: return launch_heads<bf16_t>(src, dst, B, N, H, d, D, false, s);
-        default: return LORA_E_BADARG;
-    }
+    return run_heads(src, dst, B, N, H, d, D, (int64_t)H * N * D, (int64_t)N * D, D, false, dtype, stream);
+}
+
+extern "C" int attn_merge_heads_strided(const void* src, void* dst, int B, int N, int H, int d, int D, int64_t sB,
+                                        int64_t sH, int64_t sN, int dtype, void* stream) {
+    if (sB < 0 || sH < 0 || sN < 0) return LORA_E_BADARG;
+    return run_heads(src, dst, B, N, H, d, D, sB, sH, sN, false, dtype, stream);
 }

@@ -43,14 +43,14 @@ class _SplitHeadsFn(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        return nat.attn_merge_heads(g if g.is_contiguous() else g.contiguous(), ctx.d), None, None
+        return nat.attn_merge_heads(g, ctx.d), None, None  # strided views are consumed in place
 
 
 class _MergeHeadsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, d):
         ctx.heads, ctx.D = x.shape[1], x.shape[-1]
-        return nat.attn_merge_heads(x if x.is_contiguous() else x.contiguous(), d)
+        return nat.attn_merge_heads(x, d)
 
     @staticmethod
     @once_differentiable

@@ -207,6 +207,10 @@ int geglu_gate_fwd(const void* y, void* out, int64_t M, int C, int dtype, void* 
 int geglu_gate_bwd(const void* y, const void* dout, void* dy, int64_t M, int C, int dtype, void* stream);
 int attn_split_heads(const void* src, void* dst, int B, int N, int H, int d, int D, int dtype, void* stream);
 int attn_merge_heads(const void* src, void* dst, int B, int N, int H, int d, int D, int dtype, void* stream);
+/* same, reading a [B,H,N,D] VIEW whose (b,h,n) rows start at b·sB + h·sH + n·sN elements (last dim contiguous):
+ * the attention core hands back its output and its q/k/v gradients as transposed views; this consumes them in place. */
+int attn_merge_heads_strided(const void* src, void* dst, int B, int N, int H, int d, int D, int64_t sB, int64_t sH,
+                             int64_t sN, int dtype, void* stream);
 
 /*
  * Short-context attention core  O = softmax(Q·Kᵀ·scale)·V  per head, for at most 128 keys: the cross-attention

@@ -716,6 +716,11 @@ def test_sandwich_ops_geglu_and_head_layouts(relerr, dtype):
     w = torch.randn(B, H, N, D, generator=g).to(dtype)
     s4.backward(w.to(DEV))
     assert torch.equal(xs.grad.cpu(), w[..., :d].transpose(1, 2).reshape(B, N, H * d))
+    # the attention core returns [B,H,N,D] as a transposed VIEW of [B,N,H,D]: merged in place, no contiguous() copy
+    t = torch.randn(B, N, H, D, generator=g).to(dtype)
+    view = t.to(DEV).transpose(1, 2)
+    assert not view.is_contiguous()
+    assert torch.equal(merge_heads(view, d).cpu(), t[..., :d].reshape(B, N, H * d))
 
 
 def _attention_reference(q, k, v, heads):
