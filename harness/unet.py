@@ -201,6 +201,16 @@ class Transformer2DModel(nn.Module):
         b, c, h, w = x.shape
         res = x
         x = self.norm(x)
+        if x.is_cuda and not self.linear_projection:
+            # A 1×1 convolution IS a linear layer over the channels.  On the GPU run it on the token layout the
+            # transformer blocks need anyway (one NCHW→NHWC copy in, one back): the convolution library would
+            # transpose to NHWC and back around each of the two convolutions, and handing it the permuted view
+            # leaves channels-last tensors behind that every later norm / add / convolution has to re-lay out.
+            x = F.linear(x.permute(0, 2, 3, 1).reshape(b, h * w, c), self.proj_in.weight.view(c, c), self.proj_in.bias)
+            for blk in self.transformer_blocks:
+                x = blk(x, context)
+            x = F.linear(x, self.proj_out.weight.view(c, c), self.proj_out.bias)
+            return x.view(b, h, w, c).permute(0, 3, 1, 2).contiguous() + res
         if self.linear_projection:
             x = self.proj_in(x.permute(0, 2, 3, 1).reshape(b, h * w, c))
         else:
@@ -208,7 +218,7 @@ class Transformer2DModel(nn.Module):
         for blk in self.transformer_blocks:
             x = blk(x, context)
         if self.linear_projection:
-            x = self.proj_out(x).reshape(b, h, w, c).permute(0, 3, 1, 2)
+            x = self.proj_out(x).reshape(b, h, w, c).permute(0, 3, 1, 2).contiguous()
         else:
             x = self.proj_out(x.reshape(b, h, w, c).permute(0, 3, 1, 2))
         return x + res
