@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--latent", type=int, default=64, help="latent height=width (512² images → 64)")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32"])
     ap.add_argument("--no-prof", action="store_true", help="do not attach kernel events in the timed region")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch every kernel from the host each step instead of replaying the recorded hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --shared-gpu rehearses N ranks on one GPU")
@@ -163,7 +165,9 @@ def main():
 
     dtype = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[args.dtype]
     unet = build_model(device, dtype, args.rank_r)
-    trainer = LoraTrainer(unet, lr=1e-4)
+    # forward+backward of a step are recorded once into a hipGraph (during the priming step) and replayed; the
+    # partial-sum fold, the RCCL exchange and the optimizer are launched from the host every step (trainer.py)
+    trainer = LoraTrainer(unet, lr=1e-4, capture_graph=not args.no_graph)
     data = synthetic_steps(args.warmup + args.steps, args.batch, args.latent, rank, world, device)
 
     def barrier():
@@ -201,7 +205,9 @@ def main():
     # `value`; all ranks run it so that the collectives stay matched.
     profiled = not args.no_prof
     prof, elapsed_prof = {}, None
+    graph_used = trainer.capture_graph and trainer._graph is not None
     if profiled:
+        trainer.capture_graph = False  # events attach to live dispatches: this pass launches from the host
         if rank == 0:
             nat.prof_enable(args.steps * 600)
         barrier()
@@ -220,6 +226,8 @@ def main():
     if rank == 0:
         log(f"timed region done: {1e3 * elapsed / args.steps:.2f} ms/step")
     final_loss = float(losses[-1].item())
+    if rank == 0:
+        log("losses: " + " ".join(f"{float(l.item()):.4f}" for l in losses))
     overflow = trainer.opt.overflowed()
 
     if rank == 0:
@@ -241,7 +249,8 @@ def main():
                                    f"{args.latent * 8}^2 ({args.latent}x{args.latent}x4 latents), {args.dtype} storage/compute, "
                                    "fp32 accumulate + fp32 master LoRA, full train step (fwd+bwd+clip+AdamW)",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
-                       "lora_params": trainer.slab.numel, "final_loss": final_loss, "overflow": overflow},
+                       "lora_params": trainer.slab.numel, "final_loss": final_loss, "overflow": overflow,
+                       "hipgraph": bool(graph_used)},
         }
         if prof:
             dom = max(prof.items(), key=lambda kv: kv[1]["ms"])

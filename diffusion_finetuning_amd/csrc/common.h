@@ -42,6 +42,16 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Zeroes the 16-byte ticket header of a reduction workspace with a KERNEL, not hipMemsetAsync: inside a captured
+// hipGraph a memset node is not reliably ordered before the kernel node that follows it when the graph is launched
+// into an idle queue (observed on ROCm 7.2 / gfx950: the last-arriver count of ddpm_mse_kernel was reset mid-kernel and
+// the loss came out as a partial sum), while kernel→kernel ordering holds.
+__global__ void lora_zero_ticket_kernel(unsigned* ticket);
+static inline bool lora_zero_ticket(void* workspace, hipStream_t s) {
+    hipLaunchKernelGGL(lora_zero_ticket_kernel, dim3(1), dim3(64), 0, s, static_cast<unsigned*>(workspace));
+    return hipGetLastError() == hipSuccess;
+}
+
 // Launch-profiler hooks (prof.hip).  An entry point declares the algorithmic work of its next launch with a
 // ProfWork object; LORA_LAUNCH attaches start/stop events to the dispatch itself (hipExtLaunchKernelGGL), so
 // the recorded time is the kernel's own duration, not the gap between host-side event records.

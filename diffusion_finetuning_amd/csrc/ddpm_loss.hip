@@ -187,7 +187,7 @@ extern "C" int ddpm_mse_fwd_bwd(const void* pred, const void* target, const floa
     if (n_inst < 1 || n_prior < 0 || per_row < 1 || hw < 1 || (per_row % hw) != 0) return LORA_E_BADARG;
     if (!aligned16(workspace)) return LORA_E_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(workspace, 0, 16, s) != hipSuccess) return LORA_E_LAUNCH;
+    if (!lora_zero_ticket(workspace, s)) return LORA_E_LAUNCH;
     MseParams p{};
     p.pred = pred; p.target = target; p.mask = mask; p.dpred = dpred; p.loss_out = loss_out;
     p.ticket = static_cast<unsigned*>(workspace);

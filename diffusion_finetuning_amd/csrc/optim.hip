@@ -191,7 +191,7 @@ extern "C" int lora_grad_sqnorm(const float* grad, int64_t n, float grad_mul, fl
     if (!grad || !norm_out || !workspace || n < 1) return LORA_E_BADARG;
     if (!aligned16(workspace) || !aligned16(grad)) return LORA_E_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(workspace, 0, 16, s) != hipSuccess) return LORA_E_LAUNCH;
+    if (!lora_zero_ticket(workspace, s)) return LORA_E_LAUNCH;
     int64_t blocks = (n / 4 + 255) / 256;
     if (blocks > kMaxBlocks) blocks = kMaxBlocks;
     if (blocks < 1) blocks = 1;

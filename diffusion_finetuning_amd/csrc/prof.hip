@@ -114,3 +114,7 @@ extern "C" int lora_prof_collect(lora_prof_totals* out) {
     s.used = 0;
     return LORA_OK;
 }
+
+__global__ void lora_zero_ticket_kernel(unsigned* ticket) {
+    if (threadIdx.x < 4) ticket[threadIdx.x] = 0u;
+}

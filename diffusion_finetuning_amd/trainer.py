@@ -284,8 +284,14 @@ class LoraTrainer:
 
     def __init__(self, unet: nn.Module, text_encoder: Optional[nn.Module] = None, lr=1e-4, lr_text=5e-6,
                  weight_decay=1e-2, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0, loss_scale: Optional[float] = None,
-                 v_prediction=False, process_group=None, always_reduce=False):
+                 v_prediction=False, process_group=None, always_reduce=False, capture_graph=False):
+        """capture_graph: record add_noise → UNet forward → loss → backward of a step once into a hipGraph and
+        replay it on later steps with the same shapes (inputs are copied into static buffers).  The partial-sum fold,
+        the gradient exchange and the optimizer stay outside the graph, so no collective is ever captured.  Only the
+        plain UNet step is eligible (no text-encoder LoRA, no mask); anything else runs eagerly."""
         self.unet, self.text_encoder = unet, text_encoder
+        self.capture_graph = bool(capture_graph)
+        self._graph = None
         models = [unet] + ([text_encoder] if text_encoder is not None and lora_layers(text_encoder) else [])
         self.slab = LoraSlab(models)
         groups = [{"range": self.slab.model_ranges[0], "lr": lr, "weight_decay": weight_decay}]
@@ -334,6 +340,9 @@ class LoraTrainer:
         latents) and `timesteps` (int64 [B]) — the caller drew them, as the reference does — or pass None for both and
         a `seed`: the step then draws them on the device (Philox keyed by (seed, optimizer step), identical on
         every rank) inside the prologue kernel."""
+        if self.capture_graph and mask is None and self.text_encoder is None:
+            return self._step_graph(latents, noise, timesteps, encoder_hidden_states, with_prior_preservation,
+                                    prior_loss_weight, seed)
         self.slab.zero_grad()
         self.slab.repack()  # packed compute-dtype factors follow the fp32 masters (also after external edits)
         if noise is None:
@@ -360,6 +369,83 @@ class LoraTrainer:
         self.opt.step(grad_mul=1.0 / (self.world * self.loss_scale))
         self.slab.repack()  # forwards outside step() (sampling, evaluation, saving merged weights) see the new factors
         return loss
+
+
+    # -- the same step with forward+backward replayed from a hipGraph -----------------------------------
+    def _graph_body(self, st):
+        """What is captured: reads only static buffers, leaves the factor-gradient partials and the loss behind."""
+        if st["draw"]:
+            noisy, target = st["noisy"], st["target"]
+        else:
+            noisy, target = nat.ddpm_add_noise(st["latents"], st["noise"], st["timesteps"], self.sqrt_acp,
+                                               self.sqrt_1macp, self.dtype, self.v_prediction)
+        pred = self.unet(noisy, st["timesteps"], st["ehs"]).sample
+        rows = pred.shape[0]
+        n_inst, n_prior = (rows // 2, rows // 2) if st["prior"] else (rows, 0)
+        pred_c = pred if pred.is_contiguous() else pred.contiguous()
+        loss, dpred = nat.ddpm_mse_fwd_bwd(pred_c, target, None, n_inst, n_prior, st["prior_weight"], self.loss_scale)
+        pred_c.backward(dpred)
+        st["loss"] = loss
+
+    def _graph_inputs(self, st, latents, noise, timesteps, ehs, seed):
+        if st["draw"]:
+            if seed is None:
+                raise ValueError("pass noise and timesteps, or a seed for the on-device draw")
+            noisy, target, t = nat.ddpm_noise_prologue(latents, self.sqrt_acp, self.sqrt_1macp, self.dtype, seed,
+                                                       self.opt.step_count, self.v_prediction)
+            st["noisy"].copy_(noisy)
+            st["target"].copy_(target)
+            st["timesteps"].copy_(t)
+        else:
+            st["latents"].copy_(latents)
+            st["noise"].copy_(noise)
+            st["timesteps"].copy_(timesteps)
+        st["ehs"].copy_(ehs)  # casts to the compute dtype
+        self.slab.zero_grad()
+        self.slab.repack()
+
+    def _step_graph(self, latents, noise, timesteps, ehs, prior, prior_weight, seed):
+        key = (tuple(latents.shape), tuple(ehs.shape), bool(prior), float(prior_weight), noise is None)
+        st = self._graph
+        if st is None or st["key"] != key:
+            st = {"key": key, "draw": noise is None, "prior": bool(prior), "prior_weight": float(prior_weight),
+                  "latents": torch.empty_like(latents, dtype=torch.float32),
+                  "noise": torch.empty_like(latents, dtype=torch.float32),
+                  "timesteps": torch.empty(latents.shape[0], dtype=torch.int64, device=self.device),
+                  "noisy": torch.empty_like(latents, dtype=self.dtype), "target": torch.empty_like(latents, dtype=self.dtype),
+                  "ehs": torch.empty_like(ehs, dtype=self.dtype), "graph": None}
+            self._graph_inputs(st, latents, noise, timesteps, ehs, seed)
+            try:
+                # warm up on a side stream (solver searches, lazy initialisation, allocator), then record
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        self._graph_body(st)
+                torch.cuda.current_stream().wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._graph_body(st)
+                st["graph"] = g
+            except Exception as exc:  # keep training: this trainer falls back to eager steps for good
+                import warnings
+
+                warnings.warn(f"LoraTrainer: hipGraph capture failed ({exc!r}); continuing with eager steps")
+                self.capture_graph, self._graph = False, None
+                return self.step(latents, noise, timesteps, ehs, with_prior_preservation=prior,
+                                 prior_loss_weight=prior_weight, seed=seed)
+            self._graph = st
+            # the warm-up passes left valid partial sums of THIS step's inputs, but replay once so that every step
+            # (including the first) is produced by the same recorded kernels
+        else:
+            self._graph_inputs(st, latents, noise, timesteps, ehs, seed)
+        st["graph"].replay()
+        for sink in self.slab._sinks:  # the Python backward fronts do not run on replay: nothing to check
+            sink.ran = 0
+        self.exchange.finish()
+        self.opt.step(grad_mul=1.0 / (self.world * self.loss_scale))
+        self.slab.repack()
+        return st["loss"].clone()
 
 
 def flat_lora_state(model: nn.Module, targets=None) -> torch.Tensor:

@@ -432,6 +432,81 @@ def test_rccl_bucketed_exchange_single_rank(golden_trajectory, tiny_unet_factory
         dist.destroy_process_group()
 
 
+def test_hipgraph_step_matches_eager_step(golden_trajectory, tiny_unet_factory, relerr):
+    """capture_graph=True records forward+backward once and replays it: same LoRA trajectory as launching every
+    kernel from the host — for the explicit-noise step, for the on-device draw, and under a (1-rank) RCCL group whose
+    watchdog thread is alive during the capture.  The explicit-noise run also lands on the reference trajectory."""
+    import os
+    import torch.distributed as dist
+
+    t, meta = golden_trajectory
+    cfg = json.loads(meta["plain"])
+
+    def run(graph, seeded, reduce=False):
+        unet = tiny_unet_factory(seed=cfg["unet_seed"]).to(DEV)
+        params, _ = dfa.inject_trainable_lora(unet, r=4)
+        _warm(list(itertools.chain(*params)), cfg["warm_seed"], cfg["warm_std"])
+        trainer = tr.LoraTrainer(unet, lr=cfg["lr"], capture_graph=graph, always_reduce=reduce)
+        losses = []
+        for step in range(cfg["steps"]):
+            lat, noise, ts, ctx = orc.synthetic_batch(step, cfg["batch"], cfg["latent_hw"], cfg["ctx_len"], cfg["ctx_dim"])
+            if seeded:
+                losses.append(trainer.step(lat.to(DEV), None, None, ctx.to(DEV), seed=77))
+            else:
+                losses.append(trainer.step(lat.to(DEV), noise.to(DEV), ts.to(DEV), ctx.to(DEV)))
+        assert (trainer._graph is not None) == graph  # the capture really happened (no silent eager fallback)
+        return tr.flat_lora_state(unet), torch.stack(losses)
+
+    for seeded in (False, True):
+        want, lw = run(False, seeded)
+        got, lg = run(True, seeded)
+        assert relerr(got, want) < 2e-5 and relerr(lg, lw) < 2e-5, (seeded, relerr(got, want), relerr(lg, lw))
+        if not seeded:
+            assert relerr(got, t["plain.final"]) < 1e-3
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29631")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        want, _ = run(False, False, reduce=True)
+        got, _ = run(True, False, reduce=True)
+        assert relerr(got, want) < 2e-5
+    finally:
+        dist.destroy_process_group()
+
+
+def test_hipgraph_step_at_full_size_with_idle_gaps(relerr):
+    """SD1.5-sized f16 model, device idle between steps (a host sync after each): the replayed loss and the LoRA state
+    track the eagerly launched step.  Regression test for a captured hipMemsetAsync node that was not ordered before
+    the kernel after it when the graph started on an idle queue (the loss came out as a partial sum); the reduction
+    workspaces are now zeroed by a kernel."""
+    from harness.unet import UNet2DConditionModel, sd15_config
+
+    def run(graph):
+        torch.manual_seed(0)
+        with torch.device(DEV):
+            unet = UNet2DConditionModel(sd15_config())
+        unet = unet.half()
+        unet.requires_grad_(False)
+        dfa.inject_trainable_lora(unet, r=4)
+        g = torch.Generator().manual_seed(1)
+        with torch.no_grad():
+            for up, _ in dfa.extract_lora_ups_down(unet):
+                up.weight.copy_((torch.randn(up.weight.shape, generator=g) * 0.01).to(DEV))
+        trainer = tr.LoraTrainer(unet, lr=1e-4, capture_graph=graph)
+        losses = []
+        for step in range(4):
+            lat, noise, ts, ctx = orc.synthetic_batch(step, 2, 64, 77, 768)
+            losses.append(trainer.step(lat.to(DEV), noise.to(DEV), ts.to(DEV), ctx.to(DEV)))
+            torch.cuda.synchronize()
+        assert (trainer._graph is not None) == graph
+        return tr.flat_lora_state(unet), torch.stack(losses).cpu()
+
+    want, lw = run(False)
+    got, lg = run(True)
+    assert (lw > 0.5).all() and relerr(lg, lw) < 1e-3, (lg, lw)
+    assert relerr(got, want) < 1e-3
+
+
 def test_pack_factors_and_partial_reduce_entry_points(relerr):
     """lora_pack_factors(_batched), lora_linear_bwd_params (row-block partials) and lora_reduce_partials."""
     g = torch.Generator().manual_seed(21)
