@@ -167,7 +167,10 @@ def main():
     unet = build_model(device, dtype, args.rank_r)
     # forward+backward of a step are recorded once into a hipGraph (during the priming step) and replayed; the
     # partial-sum fold, the RCCL exchange and the optimizer are launched from the host every step (trainer.py)
-    trainer = LoraTrainer(unet, lr=1e-4, capture_graph=not args.no_graph)
+    # (the gloo rehearsal backend stages the slab through the host; with a recorded graph alive in two processes on one
+    #  device that path degrades to seconds per step — before and after the recording — so it stays host-launched)
+    use_graph = not args.no_graph and (world == 1 or args.backend == "nccl")
+    trainer = LoraTrainer(unet, lr=1e-4, capture_graph=use_graph)
     data = synthetic_steps(args.warmup + args.steps, args.batch, args.latent, rank, world, device)
 
     def barrier():
@@ -181,8 +184,32 @@ def main():
     # Setup, not measurement: one throw-away step on a scratch copy of the LoRA state so that MIOpen / hipBLASLt /
     # SDPA pick (and, on a box with a cold cache, search for) their kernels before the W warm-up steps start.
     snapshot = (trainer.slab.params.clone(), trainer.opt.exp_avg.clone(), trainer.opt.exp_avg_sq.clone(), trainer.opt.step_count)
-    trainer.step(*data[0])
+    want_graph, trainer.capture_graph = trainer.capture_graph, False
+    trainer.step(*data[0])  # host-launched: solver searches and lazy initialisation happen here
     torch.cuda.synchronize()
+    if want_graph:
+        # Launch-mode selection, still setup: record the graph, then time two host-launched and two replayed steps.
+        # The graph is kept only if it is not slower, and every rank takes the same decision (the two modes issue
+        # different collectives), so an unexpected runtime interaction can cost speed but never correctness.
+        def trial(n=2):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                trainer.step(*data[0])
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n
+
+        t_host = trial()
+        trainer.capture_graph = True
+        trainer.step(*data[0])  # records (falls back to host launches by itself if the recording fails)
+        t_graph = trial() if trainer.capture_graph else float("inf")
+        keep = torch.tensor([1.0 if t_graph <= 1.05 * t_host else 0.0], device=device)
+        if world > 1:
+            dist.all_reduce(keep, op=dist.ReduceOp.MIN)
+        trainer.capture_graph = bool(keep.item() > 0)
+        if rank == 0:
+            log(f"launch mode: host {1e3 * t_host:.1f} ms/step, hipGraph {1e3 * t_graph:.1f} ms/step -> "
+                f"{'hipGraph' if trainer.capture_graph else 'host-launched'}")
     trainer.slab.params.copy_(snapshot[0]); trainer.opt.exp_avg.copy_(snapshot[1]); trainer.opt.exp_avg_sq.copy_(snapshot[2])
     trainer.opt.step_count = snapshot[3]
     del snapshot
