@@ -1,0 +1,110 @@
+"""The reference's attention hook, backed by the HIP short-context attention core.
+
+The reference switches the attention implementation of a model with
+`set_use_memory_efficient_attention_xformers(module, valid)` (lora_diffusion/xformers_utils.py:41-70, called by
+training_scripts/train_lora_dreambooth.py:623-625 under `--use_xformers`).  This module exports the same function
+with the same signature.  Instead of xformers it installs, on every attention module under `module`, a forward that
+runs `softmax(QKᵀ·scale)V` of a SHORT key/value sequence — the cross-attention over the text tokens — through
+csrc/attn_ctx.hip, directly on the [B, T, H·d] tensors its `to_q/to_k/to_v` linears (the LoRA targets,
+lora_diffusion/lora.py:53) produce.  Everything the kernel does not cover (self-attention over thousands of tokens,
+fp32 tensors, masks, CPU tensors, exotic module options) is handed back, untouched, to the module's own forward:
+the product implements what it accelerates and nothing else.
+
+Attention modules are recognised structurally, like the reference recognises LoRA targets by class name
+(lora.py:78-114): class name "CrossAttention" or "Attention" with `heads`, `to_q`, `to_k`, `to_v` and a `to_out`
+sequence — the layout of diffusers' class in every version the reference supports, and of the build's harness UNet.
+"""
+import functools
+import torch
+from torch import nn
+
+from . import _native as nat
+from .sandwich import ctx_attention
+
+ATTENTION_CLASS_NAMES = {"CrossAttention", "Attention"}
+_ORIG = "_dfa_original_forward"
+
+
+def _is_attention_module(m: nn.Module) -> bool:
+    if m.__class__.__name__ not in ATTENTION_CLASS_NAMES:
+        return False
+    if not all(hasattr(m, a) for a in ("heads", "to_q", "to_k", "to_v", "to_out")):
+        return False
+    # options whose arithmetic the short-context kernel does not reproduce: leave such modules alone
+    for attr in ("added_kv_proj_dim", "group_norm", "norm_cross", "spatial_norm"):
+        if getattr(m, attr, None) not in (None, False):
+            return False
+    return True
+
+
+def _out_features(linear: nn.Module) -> int:
+    inner = getattr(linear, "linear", linear)  # LoraInjectedLinear keeps the nn.Linear in `.linear` (lora.py:42)
+    return inner.out_features
+
+
+def _compute_dtype(x: torch.Tensor) -> torch.dtype:
+    if torch.is_autocast_enabled("cuda"):
+        return torch.get_autocast_dtype("cuda")
+    return x.dtype
+
+
+def _hip_forward(self, hidden_states, *args, **kwargs):
+    """Replacement forward.  Understands both generations of the diffusers signature — (hidden_states, context, mask)
+    and (hidden_states, encoder_hidden_states=..., attention_mask=...) — and passes anything else through."""
+    original = self.__dict__[_ORIG]
+    ctx = kwargs.get("encoder_hidden_states", kwargs.get("context", args[0] if len(args) > 0 else None))
+    mask = kwargs.get("attention_mask", kwargs.get("mask", args[1] if len(args) > 1 else None))
+    unknown = len(args) > 2 or any(k not in ("encoder_hidden_states", "context", "attention_mask", "mask") for k in kwargs)
+    heads = int(self.heads)
+    usable = (
+        not unknown and ctx is not None and mask is None and hidden_states.is_cuda and hidden_states.dim() == 3
+        and ctx.dim() == 3 and _out_features(self.to_q) % heads == 0
+        and nat.attn_ctx_supported(hidden_states.shape[0], hidden_states.shape[1], ctx.shape[1], heads,
+                                   _out_features(self.to_q) // heads, _compute_dtype(hidden_states))
+    )
+    if not usable:
+        return original(hidden_states, *args, **kwargs)
+    q, k, v = self.to_q(hidden_states), self.to_k(ctx), self.to_v(ctx)
+    if q.dtype != k.dtype:  # mixed module dtypes outside autocast: compute in the query's dtype
+        k, v = k.to(q.dtype), v.to(q.dtype)
+    scale = getattr(self, "scale", None)
+    out = ctx_attention(q, k, v, heads, float(scale) if isinstance(scale, (int, float)) else None)
+    for layer in self.to_out:  # linear (LoRA target), dropout
+        out = layer(out)
+    return out
+
+
+def set_use_hip_attention(module: nn.Module, valid: bool = True) -> int:
+    """Install (valid=True) or remove (valid=False) the HIP short-context attention forward on every attention module
+    under `module`.  Returns the number of modules touched.  Idempotent."""
+    touched = 0
+    for m in module.modules():
+        if not _is_attention_module(m):
+            continue
+        has = _ORIG in m.__dict__
+        if valid and not has:
+            m.__dict__[_ORIG] = m.forward  # the bound method (class forward, or whatever was installed before)
+            m.forward = functools.partial(_hip_forward, m)
+            touched += 1
+        elif not valid and has:
+            orig = m.__dict__.pop(_ORIG)
+            del m.forward  # drop the instance attribute: the class's forward is visible again
+            if getattr(orig, "__func__", None) is not type(m).forward:
+                m.forward = orig  # something else had been installed before us: put it back
+            touched += 1
+    return touched
+
+
+def set_use_memory_efficient_attention_xformers(module: nn.Module, valid: bool) -> None:
+    """Same name and signature as the reference's hook (lora_diffusion/xformers_utils.py:41-70), so the trainers'
+    `--use_xformers` path (train_lora_dreambooth.py:623-625) switches the HIP attention core on without edits.
+    The VAE's attention (one 4096-token self-attention per block) is outside the kernel's envelope: calling this on
+    it installs forwards that always defer to the original, exactly like the reference turns xformers off per block
+    when its probe fails (xformers_utils.py:46-60)."""
+    set_use_hip_attention(module, bool(valid))
+
+
+def test_xformers_backwards(size: int) -> bool:
+    """The reference probes whether its attention backend can differentiate a head size (xformers_utils.py:17-38).
+    Here: whether the HIP short-context kernels cover that head size for a 77-token context in f16."""
+    return bool(nat.attn_ctx_supported(1, 64, 77, 1, int(size), torch.float16))

@@ -123,18 +123,17 @@ def _attention_core(q, k, v, heads):
     memory-efficient backend).  Zero columns add nothing to QKᵀ and produce zero output columns, which are dropped
     again; the scale stays 1/√d of the true head size.  The [B,N,H·d] ↔ [B,H,N,D] re-layouts (with the padding)
     are single streaming kernels (diffusion_finetuning_amd.sandwich) instead of generic strided copies.
-    Cross-attention (≤ 128 keys, head dim ≤ 160, 16-bit) skips all of that: csrc/attn_ctx.hip works on the
-    [B,N,H·d] tensors directly."""
+    Cross-attention does not come through here once the caller has switched the HIP attention core on
+    (`set_use_memory_efficient_attention_xformers(unet, True)`, the reference's own hook): csrc/attn_ctx.hip then works
+    on the [B,N,H·d] tensors directly."""
     b, n, hd = q.shape
     d = hd // heads
     if not q.is_cuda:
         split = lambda t: t.view(b, t.shape[1], heads, d).transpose(1, 2)
         o = F.scaled_dot_product_attention(split(q), split(k), split(v))
         return o.transpose(1, 2).reshape(b, n, hd)
-    from diffusion_finetuning_amd.sandwich import ctx_attention, ctx_attention_supported, merge_heads, split_heads
+    from diffusion_finetuning_amd.sandwich import merge_heads, split_heads
 
-    if ctx_attention_supported(q, k, heads):  # cross-attention over the text tokens: one streaming HIP kernel
-        return ctx_attention(q, k, v, heads)
     D = 64 if d < 64 else (128 if d < 128 else d)
     q4, k4, v4 = split_heads(q, heads, D), split_heads(k, heads, D), split_heads(v, heads, D)
     # set_priority: without it the list only ENABLES backends and PyTorch still tries flash first, whose backward is

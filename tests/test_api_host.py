@@ -241,3 +241,36 @@ def test_save_all_safe_form(tiny_unet_factory, tmp_path):
         dfa.save_all(unet, te, [3], ["<tok>"], str(tmp_path / "all.pt"))
     dfa.save_all(unet, te, [3], ["<tok>"], str(tmp_path / "trip.pt"), safe_form=False)
     assert os.path.exists(tmp_path / "trip.text_encoder.pt") and os.path.exists(tmp_path / "trip.ti.pt")
+
+
+def test_attention_hook_patches_and_restores_without_a_gpu():
+    """The reference's attention switch (lora_diffusion/xformers_utils.py:41-70) under its own name: installs a forward
+    on attention-shaped modules only, defers to the original for tensors the HIP core does not take (here: CPU), and
+    `valid=False` restores the class forward."""
+    import torch
+    from torch import nn
+
+    import lora_diffusion.xformers_utils as xu
+    from diffusion_finetuning_amd.attention import set_use_hip_attention
+    from harness.unet import BasicTransformerBlock
+
+    torch.manual_seed(0)
+    blk = BasicTransformerBlock(32, 2, 16, 24)
+    x, ctx = torch.randn(2, 10, 32), torch.randn(2, 7, 24)
+    want = blk(x, ctx)
+    assert set_use_hip_attention(blk, True) == 2  # attn1, attn2 — not the norms / feed-forward
+    assert set_use_hip_attention(blk, True) == 0  # idempotent
+    assert torch.equal(blk(x, ctx), want)  # CPU tensors: handed back to the module's own forward
+    xu.set_use_memory_efficient_attention_xformers(blk, False)
+    assert all("forward" not in m.__dict__ for m in blk.modules())
+    assert torch.equal(blk(x, ctx), want)
+
+    class Attention(nn.Module):  # look-alike with an option the kernel does not reproduce: must be left alone
+        def __init__(self):
+            super().__init__()
+            self.heads, self.group_norm = 2, nn.GroupNorm(2, 8)
+            self.to_q = self.to_k = self.to_v = nn.Linear(8, 8)
+            self.to_out = nn.ModuleList([nn.Linear(8, 8), nn.Dropout(0.0)])
+
+    assert set_use_hip_attention(Attention(), True) == 0
+    assert callable(xu.test_xformers_backwards) and callable(xu.set_use_hip_attention)

@@ -857,11 +857,13 @@ def test_ctx_attention_is_deterministic_and_rejects_what_it_does_not_cover():
         nat.attn_ctx_fwd(q.detach().float(), k.detach().float(), v.detach().float(), 8, 0.1)
 
 
-def test_harness_cross_attention_uses_the_hip_core_and_matches_stock(relerr):
-    """The harness transformer block routes its cross-attention through ctx_attention; the block's output and the
-    LoRA gradients agree with the same block run through stock SDPA."""
+def test_attention_hook_routes_cross_attention_through_the_hip_core(relerr):
+    """`set_use_memory_efficient_attention_xformers(model, True)` — the reference's own switch
+    (lora_diffusion/xformers_utils.py:41-70) — sends the cross-attention of a transformer block through ctx_attention
+    and leaves self-attention to the module; output and LoRA gradients agree with the un-hooked block; `False` undoes it."""
     import harness.unet as hu
-    from diffusion_finetuning_amd import sandwich
+    from diffusion_finetuning_amd import attention, sandwich
+    from lora_diffusion.xformers_utils import set_use_memory_efficient_attention_xformers as hook
 
     torch.manual_seed(5)
     blk = hu.BasicTransformerBlock(320, 8, 40, 768).to(DEV).half()
@@ -874,33 +876,32 @@ def test_harness_cross_attention_uses_the_hip_core_and_matches_stock(relerr):
                 p.copy_(torch.randn_like(p) * 0.02)
     x = torch.randn(2, 256, 320, device=DEV).half()
     ctx = torch.randn(2, 77, 768, device=DEV).half()
-    calls = []
-    real = sandwich.ctx_attention
 
-    def spy(*a, **kw):
-        calls.append(1)
-        return real(*a, **kw)
-
-    sandwich.ctx_attention = spy
-    try:
+    def run():
+        for p in plist:
+            p.grad = None
         out = blk(x, ctx)
         out.float().pow(2).sum().mul(1e-2).backward()
-    finally:
-        sandwich.ctx_attention = real
-    assert len(calls) == 1  # attn2 only: attn1 has 256 keys
-    grads = [p.grad.clone() for p in plist]
-    for p in plist:
-        p.grad = None
-    supported = sandwich.ctx_attention_supported
-    sandwich.ctx_attention_supported = lambda *a, **kw: False
+        return out, [p.grad.clone() for p in plist]
+
+    ref, ref_grads = run()
+    calls = []
+    real = attention.ctx_attention
+    attention.ctx_attention = lambda *a, **kw: (calls.append(1), real(*a, **kw))[1]
     try:
-        ref = blk(x, ctx)
-        ref.float().pow(2).sum().mul(1e-2).backward()
+        hook(blk, True)
+        hook(blk, True)  # idempotent
+        out, grads = run()
     finally:
-        sandwich.ctx_attention_supported = supported
+        attention.ctx_attention = real
+    assert len(calls) == 1  # attn2 only: attn1 has no context and 256 keys, it went to the module's own forward
     assert relerr(out, ref) < 2e-3
-    for a, p in zip(grads, plist):
-        assert relerr(a, p.grad) < 2e-2
+    for a, b in zip(grads, ref_grads):
+        assert relerr(a, b) < 2e-2
+    hook(blk, False)
+    assert all("forward" not in m.__dict__ for m in blk.modules())
+    out2, _ = run()
+    assert torch.equal(out2, ref)
 
 
 def test_drop_in_under_ddp_autocast_and_checkpointing(golden_trajectory, tiny_unet_factory, relerr):
