@@ -54,9 +54,10 @@ def build_model(device, dtype, rank_r):
     unet = unet.to(dtype)
     unet.requires_grad_(False)  # train_lora_dreambooth.py:595
     dfa.inject_trainable_lora(unet, r=rank_r)  # :596-598
-    from diffusion_finetuning_amd.attention import set_use_memory_efficient_attention_xformers
+    from diffusion_finetuning_amd.attention import set_use_hip_geglu, set_use_memory_efficient_attention_xformers
 
     set_use_memory_efficient_attention_xformers(unet, True)  # :623-624 (--use_xformers): here the HIP attention core
+    set_use_hip_geglu(unet, True)  # the fused GEGLU gate after each `proj` LoRA linear
     g = torch.Generator(device="cpu").manual_seed(1)
     with torch.no_grad():  # warm-started `up` so no kernel sees the all-zero branch
         for up, _ in dfa.extract_lora_ups_down(unet):

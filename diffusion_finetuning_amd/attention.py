@@ -95,6 +95,38 @@ def set_use_hip_attention(module: nn.Module, valid: bool = True) -> int:
     return touched
 
 
+def _hip_geglu_forward(self, hidden_states, *args, **kwargs):
+    """diffusers GEGLU.forward: `hidden, gate = proj(x).chunk(2, -1); hidden * gelu(gate)` — here one fused pass
+    after the `proj` LoRA linear (and one in backward)."""
+    if args or kwargs or not hidden_states.is_cuda:
+        return self.__dict__[_ORIG](hidden_states, *args, **kwargs)
+    from .sandwich import geglu_gate
+
+    return geglu_gate(self.proj(hidden_states))
+
+
+def set_use_hip_geglu(module: nn.Module, valid: bool = True) -> int:
+    """Install / remove the fused GEGLU gate on every module whose class is named "GEGLU" (the LoRA target class of
+    lora_diffusion/lora.py:53) and that has a `proj` linear.  The reference has no switch for this op; a trainer that
+    wants it adds one line next to its `--use_xformers` line.  Returns the number of modules touched."""
+    touched = 0
+    for m in module.modules():
+        if m.__class__.__name__ != "GEGLU" or not hasattr(m, "proj"):
+            continue
+        has = _ORIG in m.__dict__
+        if valid and not has:
+            m.__dict__[_ORIG] = m.forward
+            m.forward = functools.partial(_hip_geglu_forward, m)
+            touched += 1
+        elif not valid and has:
+            orig = m.__dict__.pop(_ORIG)
+            del m.forward
+            if getattr(orig, "__func__", None) is not type(m).forward:
+                m.forward = orig
+            touched += 1
+    return touched
+
+
 def set_use_memory_efficient_attention_xformers(module: nn.Module, valid: bool) -> None:
     """Same name and signature as the reference's hook (lora_diffusion/xformers_utils.py:41-70), so the trainers'
     `--use_xformers` path (train_lora_dreambooth.py:623-625) switches the HIP attention core on without edits.

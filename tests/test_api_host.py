@@ -274,3 +274,8 @@ def test_attention_hook_patches_and_restores_without_a_gpu():
 
     assert set_use_hip_attention(Attention(), True) == 0
     assert callable(xu.test_xformers_backwards) and callable(xu.set_use_hip_attention)
+    # the GEGLU switch: one module in the block; CPU tensors go back to the stock composite; undo restores the class
+    assert xu.set_use_hip_geglu(blk, True) == 1 and xu.set_use_hip_geglu(blk, True) == 0
+    assert torch.equal(blk(x, ctx), want)
+    assert xu.set_use_hip_geglu(blk, False) == 1
+    assert all("forward" not in m.__dict__ for m in blk.modules())
