@@ -112,7 +112,14 @@ def dtype_code(dtype: torch.dtype) -> int:
         raise RuntimeError(f"diffusion_finetuning_amd: unsupported dtype {dtype} (float32, float16, bfloat16 only)")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(t: torch.Tensor) -> int:
+    """hipStream_t of the calling thread's current stream on t's device (the raw-handle query when this PyTorch has
+    it: building a torch.cuda.Stream object per launch costs ~2 µs of host time, ~700 times per step)."""
+    if _raw_stream is not None:
+        return _raw_stream(t.device.index)
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
