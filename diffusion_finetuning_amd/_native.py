@@ -60,6 +60,10 @@ SIGNATURES = {
     "attn_ctx_fwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "attn_ctx_bwd_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
     "attn_ctx_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "attn_flash_supported": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32]),
+    "attn_flash_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "attn_flash_bwd_workspace_bytes": (_i64, [_i32, _i32, _i32]),
+    "attn_flash_bwd": (_i32, [_vp] * 10 + [_i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "lora_prof_enable": (_i32, [_i32]),
     "lora_prof_collect": (_i32, [ctypes.POINTER(ProfTotals)]),
     "lora_prof_kernel_name": (ctypes.c_char_p, [_i32]),
@@ -417,6 +421,37 @@ def attn_ctx_bwd(q, k, v, dout, heads: int, scale: float):
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     _check(lib().attn_ctx_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(dout), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(ws), B, Tq, Tk,
                               heads, d, float(scale), dtype_code(q.dtype), _stream(q)), "attn_ctx_bwd")
+    return dq, dk, dv
+
+
+def attn_flash_supported(B: int, Tq: int, Tk: int, H: int, d: int, dtype) -> bool:
+    if dtype not in (torch.float16, torch.bfloat16):
+        return False
+    return bool(lib().attn_flash_supported(B, Tq, Tk, H, d, dtype_code(dtype)))
+
+
+def attn_flash_fwd(q, k, v, heads: int, scale: float, want_lse: bool = True):
+    """q [B,Tq,H·d], k/v [B,Tk,H·d] contiguous → (o [B,Tq,H·d], lse [B,H,Tq] fp32 | None)."""
+    _require_device(q, k, v)
+    B, Tq, HD = q.shape
+    Tk = k.shape[1]
+    out = torch.empty_like(q)
+    lse = torch.empty((B, heads, Tq), dtype=torch.float32, device=q.device) if want_lse else None
+    _check(lib().attn_flash_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, Tq, Tk, heads, HD // heads,
+                                float(scale), dtype_code(q.dtype), _stream(q)), "attn_flash_fwd")
+    return out, lse
+
+
+def attn_flash_bwd(q, k, v, out, dout, lse, heads: int, scale: float):
+    """→ (dq, dk, dv), same layouts as the inputs."""
+    _require_device(q, k, v, out, dout, lse)
+    B, Tq, HD = q.shape
+    Tk = k.shape[1]
+    ws = torch.empty(lib().attn_flash_bwd_workspace_bytes(B, Tq, heads) // 4, dtype=torch.float32, device=q.device)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    _check(lib().attn_flash_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dq), _ptr(dk),
+                                _ptr(dv), _ptr(ws), B, Tq, Tk, heads, HD // heads, float(scale), dtype_code(q.dtype),
+                                _stream(q)), "attn_flash_bwd")
     return dq, dk, dv
 
 

@@ -4,11 +4,12 @@ The reference switches the attention implementation of a model with
 `set_use_memory_efficient_attention_xformers(module, valid)` (lora_diffusion/xformers_utils.py:41-70, called by
 training_scripts/train_lora_dreambooth.py:623-625 under `--use_xformers`).  This module exports the same function
 with the same signature.  Instead of xformers it installs, on every attention module under `module`, a forward that
-runs `softmax(QKᵀ·scale)V` of a SHORT key/value sequence — the cross-attention over the text tokens — through
-csrc/attn_ctx.hip, directly on the [B, T, H·d] tensors its `to_q/to_k/to_v` linears (the LoRA targets,
-lora_diffusion/lora.py:53) produce.  Everything the kernel does not cover (self-attention over thousands of tokens,
-fp32 tensors, masks, CPU tensors, exotic module options) is handed back, untouched, to the module's own forward:
-the product implements what it accelerates and nothing else.
+runs `softmax(QKᵀ·scale)V` through the HIP attention cores — csrc/attn_ctx.hip for a short key/value sequence (the
+cross-attention over the text tokens), csrc/attn_flash.hip for a long one (self-attention over thousands of tokens) —
+directly on the [B, T, H·d] tensors its `to_q/to_k/to_v` linears (the LoRA targets, lora_diffusion/lora.py:53)
+produce.  Everything the kernels do not cover (fp32 tensors, head dims above 160, masks, CPU tensors, exotic module
+options) is handed back, untouched, to the module's own forward: the product implements what it accelerates and nothing
+else.
 
 Attention modules are recognised structurally, like the reference recognises LoRA targets by class name
 (lora.py:78-114): class name "CrossAttention" or "Attention" with `heads`, `to_q`, `to_k`, `to_v` and a `to_out`
@@ -19,7 +20,7 @@ import torch
 from torch import nn
 
 from . import _native as nat
-from .sandwich import ctx_attention
+from .sandwich import ctx_attention, flash_attention
 
 ATTENTION_CLASS_NAMES = {"CrossAttention", "Attention"}
 _ORIG = "_dfa_original_forward"
@@ -56,19 +57,24 @@ def _hip_forward(self, hidden_states, *args, **kwargs):
     mask = kwargs.get("attention_mask", kwargs.get("mask", args[1] if len(args) > 1 else None))
     unknown = len(args) > 2 or any(k not in ("encoder_hidden_states", "context", "attention_mask", "mask") for k in kwargs)
     heads = int(self.heads)
-    usable = (
-        not unknown and ctx is not None and mask is None and hidden_states.is_cuda and hidden_states.dim() == 3
-        and ctx.dim() == 3 and _out_features(self.to_q) % heads == 0
-        and nat.attn_ctx_supported(hidden_states.shape[0], hidden_states.shape[1], ctx.shape[1], heads,
-                                   _out_features(self.to_q) // heads, _compute_dtype(hidden_states))
-    )
-    if not usable:
+    if ctx is None:
+        ctx = hidden_states  # self-attention
+    core = None
+    if (not unknown and mask is None and hidden_states.is_cuda and hidden_states.dim() == 3 and ctx.dim() == 3
+            and _out_features(self.to_q) % heads == 0):
+        shape = (hidden_states.shape[0], hidden_states.shape[1], ctx.shape[1], heads, _out_features(self.to_q) // heads,
+                 _compute_dtype(hidden_states))
+        if nat.attn_ctx_supported(*shape):      # up to 128 keys: the whole K/V of a head in LDS, one tile
+            core = ctx_attention
+        elif nat.attn_flash_supported(*shape):  # any length: online softmax over key tiles
+            core = flash_attention
+    if core is None:
         return original(hidden_states, *args, **kwargs)
     q, k, v = self.to_q(hidden_states), self.to_k(ctx), self.to_v(ctx)
     if q.dtype != k.dtype:  # mixed module dtypes outside autocast: compute in the query's dtype
         k, v = k.to(q.dtype), v.to(q.dtype)
     scale = getattr(self, "scale", None)
-    out = ctx_attention(q, k, v, heads, float(scale) if isinstance(scale, (int, float)) else None)
+    out = core(q, k, v, heads, float(scale) if isinstance(scale, (int, float)) else None)
     for layer in self.to_out:  # linear (LoRA target), dropout
         out = layer(out)
     return out
@@ -129,14 +135,13 @@ def set_use_hip_geglu(module: nn.Module, valid: bool = True) -> int:
 
 def set_use_memory_efficient_attention_xformers(module: nn.Module, valid: bool) -> None:
     """Same name and signature as the reference's hook (lora_diffusion/xformers_utils.py:41-70), so the trainers'
-    `--use_xformers` path (train_lora_dreambooth.py:623-625) switches the HIP attention core on without edits.
-    The VAE's attention (one 4096-token self-attention per block) is outside the kernel's envelope: calling this on
-    it installs forwards that always defer to the original, exactly like the reference turns xformers off per block
-    when its probe fails (xformers_utils.py:46-60)."""
+    `--use_xformers` path (train_lora_dreambooth.py:623-625) switches the HIP attention cores on without edits.
+    Modules or calls outside the kernels' envelope (e.g. the VAE's 512-wide single head) keep deferring to their own
+    forward, like the reference turns xformers off per block when its probe fails (xformers_utils.py:46-60)."""
     set_use_hip_attention(module, bool(valid))
 
 
 def test_xformers_backwards(size: int) -> bool:
     """The reference probes whether its attention backend can differentiate a head size (xformers_utils.py:17-38).
-    Here: whether the HIP short-context kernels cover that head size for a 77-token context in f16."""
-    return bool(nat.attn_ctx_supported(1, 64, 77, 1, int(size), torch.float16))
+    Here: whether the HIP attention kernels cover that head size in f16."""
+    return bool(nat.attn_flash_supported(1, 64, 64, 1, int(size), torch.float16))

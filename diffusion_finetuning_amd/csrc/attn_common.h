@@ -1,0 +1,82 @@
+// Device helpers shared by the attention kernels (attn_ctx.hip: one key tile; attn_flash.hip: many).
+#pragma once
+#include "common.h"
+
+namespace {
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Mma;
+template <> struct Mma<half_t> {
+    using F8 = f16x8;
+    static __device__ __forceinline__ f32x4 k32(F8 a, F8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 k16(const half_t* a, const half_t* b, f32x4 c) {
+        const f16x4 av = {a[0], a[1], a[2], a[3]}, bv = {b[0], b[1], b[2], b[3]};
+        return __builtin_amdgcn_mfma_f32_16x16x16f16(av, bv, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<bf16_t> {
+    using F8 = bf16x8;
+    static __device__ __forceinline__ f32x4 k32(F8 a, F8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 k16(const bf16_t* a, const bf16_t* b, f32x4 c) {
+        s16x4 av, bv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            av[e] = __builtin_bit_cast(short, a[e]);
+            bv[e] = __builtin_bit_cast(short, b[e]);
+        }
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bv, c, 0, 0, 0);
+    }
+};
+
+template <typename T> struct alignas(8) Quad4 { T v[4]; };
+
+// position of a key inside the permuted key axis: fragments 2k and 2k+1 interleave in groups of four, which is the
+// order in which a lane's accumulator registers of two neighbouring S fragments form one 8-wide MFMA operand
+__device__ __forceinline__ int key_pos(int key) {
+    return (key & ~31) | (((key >> 2) & 3) << 3) | (((key >> 4) & 1) << 2) | (key & 3);
+}
+
+// 16-byte load that is never predicated (a predicated load costs a branch and a full wait per load on this
+// compiler): the caller passes an address that is valid either way, the value is zeroed afterwards when !ok
+template <typename T> __device__ __forceinline__ Chunk<T> load_or_zero(const T* p, bool ok) {
+    Chunk<T> v = *reinterpret_cast<const Chunk<T>*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v.v[e] = ok ? v.v[e] : from_f32<T>(0.f);
+    return v;
+}
+
+// row fragments (second MFMA operand: lane = (row l15, 8 consecutive head-dim values at ks*32 + lq*8)).
+// `safe` is any valid address of the tensor: rows past the end are read from there and zeroed.
+template <typename T, int KS>
+__device__ __forceinline__ void load_row_frags(const T* base, const T* safe, bool valid, int d, int lq,
+                                               typename Mma<T>::F8 (&f)[KS]) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int c = ks * 32 + lq * 8;
+        const bool ok = valid && c < d;
+        const Chunk<T> v = load_or_zero<T>(ok ? base + c : safe, ok);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[ks][e] = v.v[e];
+    }
+}
+
+// two neighbouring accumulator fragments → one 8-wide operand over 32 (permuted) keys
+template <typename T>
+__device__ __forceinline__ typename Mma<T>::F8 pair_frag(const f32x4& a, const f32x4& b) {
+    typename Mma<T>::F8 f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f[e] = from_f32<T>(a[e]);
+        f[4 + e] = from_f32<T>(b[e]);
+    }
+    return f;
+}
+
+
+}  // namespace

@@ -1,0 +1,706 @@
+// Long-context attention core for gfx950:  O = softmax(Q·Kᵀ·scale)·V  per head with an online softmax over key
+// tiles — the self-attention (`attn1`) of every transformer block, 4096 / 1024 / 256 / 64 tokens in the SD UNets
+// (the op between the to_q/to_k/to_v and to_out LoRA linears; diffusers CrossAttention.forward).
+//
+// Same conventions as attn_ctx.hip: tensors stay [B, T, H·d] (what the LoRA linears produce and consume), MFMA 16x16x32
+// with the key fragment as the FIRST operand so that a lane owns one query row (softmax statistics are per lane, two
+// cross-lane steps per reduction) and the probability registers feed the P·V product directly; V is staged transposed
+// with the keys permuted to that register order.  New here: 64-key tiles double-buffered in LDS (global → registers
+// at the top of an iteration, registers → LDS after the tile's arithmetic), running max / sum with accumulator
+// rescaling, several 16-row blocks per wave so that every K / V fragment read from LDS is used RB times, and the
+// row-wise log-sum-exp (base 2, of the scaled scores) written out for the backward kernels.
+#include <cstdlib>
+
+#include "attn_common.h"
+
+namespace {
+
+constexpr int kTile = 64;          // keys per tile
+constexpr int kNKF = kTile / 16;   // key fragments per tile
+
+template <int KS, int DF> struct FlashShape {
+    static constexpr int DP = KS * 32;
+    static constexpr int DV = DF * 16;
+    static constexpr int KROW = DP + 8;     // halfs per K row in LDS (+16 B against bank conflicts)
+    static constexpr int TROW = kTile + 8;  // halfs per Vᵀ row
+    static constexpr int CPR = DP / 8;      // 16-byte chunks per key row
+    static constexpr int N = kTile * CPR;
+    static constexpr int IT = (N + 255) / 256;
+    static constexpr int K_HALFS = kTile * KROW;
+    static constexpr int V_HALFS = DV * TROW;
+};
+
+// one 64-key tile of K and V on its way global → registers → LDS
+template <typename T, int KS, int DF> struct TileRegs {
+    using S = FlashShape<KS, DF>;
+    Chunk<T> k[S::IT], v[S::IT];
+    __device__ __forceinline__ void load(const T* Kh, const T* Vh, int64_t HD, int key0, int Tk, int d) {
+#pragma unroll
+        for (int i = 0; i < S::IT; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            const int key = idx / S::CPR, c = (idx - key * S::CPR) * 8;
+            const bool ok = idx < S::N && key0 + key < Tk && c < d;
+            const int64_t off = ok ? (int64_t)(key0 + key) * HD + c : 0;
+            k[i] = load_or_zero<T>(Kh + off, ok);
+            v[i] = load_or_zero<T>(Vh + off, ok);
+        }
+    }
+    __device__ __forceinline__ void store(T* Ks, T* Vt) const {
+#pragma unroll
+        for (int i = 0; i < S::IT; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            const int key = idx / S::CPR, c = (idx - key * S::CPR) * 8;
+            if (idx < S::N) {
+                *reinterpret_cast<Chunk<T>*>(Ks + key * S::KROW + c) = k[i];
+                if (c < S::DV) {
+                    const int pos = key_pos(key);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) Vt[(c + e) * S::TROW + pos] = v[i].v[e];
+                }
+            }
+        }
+    }
+};
+
+// v_exp_f32 without the library's denormal-range fix-ups (arguments here are <= 0; tiny results may flush to zero)
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+template <typename T, int KS, int DF, int RB>
+__global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
+                                                              const T* __restrict__ V, T* __restrict__ O,
+                                                              float* __restrict__ LSE, int Tq, int Tk, int H, int d,
+                                                              float scale_log2e) {
+    using S = FlashShape<KS, DF>;
+    using F8 = typename Mma<T>::F8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Ks = reinterpret_cast<T*>(smem);            // [2][kTile][KROW]
+    T* Vt = Ks + 2 * S::K_HALFS;                    // [2][DV][TROW]
+
+    const int bh = blockIdx.y;
+    const int b = bh / H, h = bh - b * H;
+    const int64_t HD = (int64_t)H * d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const T* Qh = Q + (int64_t)b * Tq * HD + h * d;
+    const T* Kh = K + (int64_t)b * Tk * HD + h * d;
+    const T* Vh = V + (int64_t)b * Tk * HD + h * d;
+
+    const int row0 = blockIdx.x * (64 * RB) + wave * (16 * RB);  // first query row of this wave
+    F8 qf[RB][KS];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int t = row0 + rb * 16 + l15;
+        load_row_frags<T, KS>(Qh + (int64_t)t * HD, Qh, t < Tq, d, lq, qf[rb]);
+    }
+    f32x4 o[RB][DF];
+    float m[RB], l[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        m[rb] = -INFINITY;
+        l[rb] = 0.f;
+#pragma unroll
+        for (int df = 0; df < DF; ++df) o[rb][df] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    TileRegs<T, KS, DF> stage;
+    stage.load(Kh, Vh, HD, 0, Tk, d);
+    stage.store(Ks, Vt);
+    __syncthreads();
+    const int n_tiles = (Tk + kTile - 1) / kTile;
+    for (int kt = 0; kt < n_tiles; ++kt) {
+        const int cur = kt & 1;
+        const T* Kc = Ks + cur * S::K_HALFS;
+        const T* Vc = Vt + cur * S::V_HALFS;
+        if (kt + 1 < n_tiles) stage.load(Kh, Vh, HD, (kt + 1) * kTile, Tk, d);  // in flight during this tile's work
+
+        // ---- Sᵀ = K·Qᵀ: every K fragment read once, used for all RB row blocks -----------------
+        f32x4 s[RB][kNKF];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int nf = 0; nf < kNKF; ++nf) s[rb][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nf = 0; nf < kNKF; ++nf)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const F8 kf = *reinterpret_cast<const F8*>(Kc + (nf * 16 + l15) * S::KROW + ks * 32 + lq * 8);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) s[rb][nf] = Mma<T>::k32(kf, qf[rb][ks], s[rb][nf]);
+            }
+        // ---- online softmax, one query row per lane (raw scores stay unscaled: exp2(s·c − m) is one fma + v_exp) ----
+        if ((kt + 1) * kTile > Tk) {  // the ragged last tile: keys past Tk never win the max and get probability 0
+            const int key_base = kt * kTile + lq * 4;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int nf = 0; nf < kNKF; ++nf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (key_base + nf * 16 + r >= Tk) s[rb][nf][r] = -INFINITY;
+        }
+        F8 pf[RB][kNKF / 2];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            float mt = -INFINITY;
+#pragma unroll
+            for (int nf = 0; nf < kNKF; ++nf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mt = fmaxf(mt, s[rb][nf][r]);
+            mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            const float m_new = fmaxf(m[rb], mt * scale_log2e);  // scale > 0: max commutes with the scaling
+            const float alpha = fast_exp2(m[rb] - m_new);
+            float sum = 0.f;
+#pragma unroll
+            for (int nf = 0; nf < kNKF; ++nf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = fast_exp2(fmaf(s[rb][nf][r], scale_log2e, -m_new));
+                    s[rb][nf][r] = p;
+                    sum += p;
+                }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            l[rb] = l[rb] * alpha + sum;
+            m[rb] = m_new;
+#pragma unroll
+            for (int df = 0; df < DF; ++df) o[rb][df] *= alpha;
+#pragma unroll
+            for (int kk = 0; kk < kNKF / 2; ++kk) pf[rb][kk] = pair_frag<T>(s[rb][2 * kk], s[rb][2 * kk + 1]);
+        }
+        // ---- Oᵀ += Vᵀ·Pᵀ -------------------------------------------------------------------------------------
+#pragma unroll
+        for (int df = 0; df < DF; ++df)
+#pragma unroll
+            for (int kk = 0; kk < kNKF / 2; ++kk) {
+                const F8 vf = *reinterpret_cast<const F8*>(Vc + (df * 16 + l15) * S::TROW + kk * 32 + lq * 8);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) o[rb][df] = Mma<T>::k32(vf, pf[rb][kk], o[rb][df]);
+            }
+        if (kt + 1 < n_tiles) stage.store(Ks + (cur ^ 1) * S::K_HALFS, Vt + (cur ^ 1) * S::V_HALFS);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int t = row0 + rb * 16 + l15;
+        if (t >= Tq) continue;
+        const float inv = 1.f / l[rb];
+        T* orow = O + ((int64_t)b * Tq + t) * HD + h * d;
+#pragma unroll
+        for (int df = 0; df < DF; ++df) {
+            const int c = df * 16 + lq * 4;
+            if (c < d) {
+                Quad4<T> out;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out.v[r] = from_f32<T>(o[rb][df][r] * inv);
+                *reinterpret_cast<Quad4<T>*>(orow + c) = out;
+            }
+        }
+        if (lq == 0 && LSE != nullptr) LSE[(int64_t)bh * Tq + t] = m[rb] + log2f(l[rb]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Backward.  Three launches, no atomics, every output element written by exactly one workgroup:
+//   delta  : Δ[b,h,q] = Σ_c dO·O            (the softmax correction, one streaming pass)
+//   dQ     : query-owned like the forward — P is rebuilt from the saved log-sum-exp, dPᵀ = V·dOᵀ has the layout of
+//            Sᵀ, dS = P∘(dP − Δ)·scale feeds dQᵀ += Kᵀ·dSᵀ straight from registers (K staged a second time transposed)
+//   dK, dV : key-owned — a wave keeps the K and V fragments of its keys in registers and walks over ALL query tiles
+//            (Q, dO, LSE, Δ staged in LDS, shared by the four waves); S = Q·Kᵀ is taken with the query fragment FIRST,
+//            so its accumulators already are MFMA 16x16x16 operands with the keys along the lanes and four query rows
+//            per lane — exactly what the contractions over the query rows (dV = Pᵀ·dO, dK = dSᵀ·Q) need.
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_flash_delta_kernel(const T* __restrict__ O, const T* __restrict__ dO,
+                                                                float* __restrict__ Delta, int B, int Tq, int H, int d) {
+    const int64_t total = (int64_t)B * Tq * H;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int h = (int)(i % H);
+        const int64_t bt = i / H;  // b*Tq + t
+        const T* o = O + bt * H * d + (int64_t)h * d;
+        const T* g = dO + bt * H * d + (int64_t)h * d;
+        float acc = 0.f;
+        for (int c = 0; c < d; c += 8) {
+            const Chunk<T> a = *reinterpret_cast<const Chunk<T>*>(o + c);
+            const Chunk<T> b = *reinterpret_cast<const Chunk<T>*>(g + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = fmaf(to_f32<T>(a.v[e]), to_f32<T>(b.v[e]), acc);
+        }
+        const int64_t b_ = bt / Tq, t = bt - b_ * Tq;
+        Delta[(b_ * H + h) * Tq + t] = acc;
+    }
+}
+
+// K and V tile for the dQ kernel: K row-major + K transposed (permuted keys), V row-major
+template <typename T, int KS, int DF> struct TileRegsDq {
+    using S = FlashShape<KS, DF>;
+    Chunk<T> k[S::IT], v[S::IT];
+    __device__ __forceinline__ void load(const T* Kh, const T* Vh, int64_t HD, int key0, int Tk, int d) {
+#pragma unroll
+        for (int i = 0; i < S::IT; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            const int key = idx / S::CPR, c = (idx - key * S::CPR) * 8;
+            const bool ok = idx < S::N && key0 + key < Tk && c < d;
+            const int64_t off = ok ? (int64_t)(key0 + key) * HD + c : 0;
+            k[i] = load_or_zero<T>(Kh + off, ok);
+            v[i] = load_or_zero<T>(Vh + off, ok);
+        }
+    }
+    __device__ __forceinline__ void store(T* Ks, T* Vs, T* Kt) const {
+#pragma unroll
+        for (int i = 0; i < S::IT; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            const int key = idx / S::CPR, c = (idx - key * S::CPR) * 8;
+            if (idx < S::N) {
+                *reinterpret_cast<Chunk<T>*>(Ks + key * S::KROW + c) = k[i];
+                *reinterpret_cast<Chunk<T>*>(Vs + key * S::KROW + c) = v[i];
+                if (c < S::DV) {
+                    const int pos = key_pos(key);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) Kt[(c + e) * S::TROW + pos] = k[i].v[e];
+                }
+            }
+        }
+    }
+};
+
+template <typename T, int KS, int DF, int RB>
+__global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const T* __restrict__ Q, const T* __restrict__ K,
+                                                             const T* __restrict__ V, const T* __restrict__ dO,
+                                                             const float* __restrict__ LSE,
+                                                             const float* __restrict__ Delta, T* __restrict__ dQ, int Tq,
+                                                             int Tk, int H, int d, float scale, float scale_log2e) {
+    using S = FlashShape<KS, DF>;
+    using F8 = typename Mma<T>::F8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Ks = reinterpret_cast<T*>(smem);   // [2][kTile][KROW]
+    T* Vs = Ks + 2 * S::K_HALFS;           // [2][kTile][KROW]
+    T* Kt = Vs + 2 * S::K_HALFS;           // [2][DV][TROW]
+
+    const int bh = blockIdx.y;
+    const int b = bh / H, h = bh - b * H;
+    const int64_t HD = (int64_t)H * d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const T* Kh = K + (int64_t)b * Tk * HD + h * d;
+    const T* Vh = V + (int64_t)b * Tk * HD + h * d;
+    const int row0 = blockIdx.x * (64 * RB) + wave * (16 * RB);
+
+    F8 qf[RB][KS], gf[RB][KS];
+    float lse[RB], delta[RB];
+    f32x4 acc[RB][DF];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int t = row0 + rb * 16 + l15;
+        const bool valid = t < Tq;
+        const int64_t roff = ((int64_t)b * Tq + t) * HD + h * d;
+        load_row_frags<T, KS>(Q + roff, Q, valid, d, lq, qf[rb]);
+        load_row_frags<T, KS>(dO + roff, dO, valid, d, lq, gf[rb]);
+        lse[rb] = valid ? LSE[(int64_t)bh * Tq + t] : INFINITY;  // +inf: probability 0 for rows past the end
+        delta[rb] = valid ? Delta[(int64_t)bh * Tq + t] : 0.f;
+#pragma unroll
+        for (int df = 0; df < DF; ++df) acc[rb][df] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    TileRegsDq<T, KS, DF> stage;
+    stage.load(Kh, Vh, HD, 0, Tk, d);
+    stage.store(Ks, Vs, Kt);
+    __syncthreads();
+    const int n_tiles = (Tk + kTile - 1) / kTile;
+    for (int kt = 0; kt < n_tiles; ++kt) {
+        const int cur = kt & 1;
+        const T* Kc = Ks + cur * S::K_HALFS;
+        const T* Vc = Vs + cur * S::K_HALFS;
+        const T* Ktc = Kt + cur * S::V_HALFS;
+        if (kt + 1 < n_tiles) stage.load(Kh, Vh, HD, (kt + 1) * kTile, Tk, d);
+
+        f32x4 s[RB][kNKF], dp[RB][kNKF];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int nf = 0; nf < kNKF; ++nf) s[rb][nf] = dp[rb][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nf = 0; nf < kNKF; ++nf)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int off = (nf * 16 + l15) * S::KROW + ks * 32 + lq * 8;
+                const F8 kf = *reinterpret_cast<const F8*>(Kc + off);
+                const F8 vf = *reinterpret_cast<const F8*>(Vc + off);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    s[rb][nf] = Mma<T>::k32(kf, qf[rb][ks], s[rb][nf]);
+                    dp[rb][nf] = Mma<T>::k32(vf, gf[rb][ks], dp[rb][nf]);
+                }
+            }
+        const bool ragged = (kt + 1) * kTile > Tk;
+        const int key_base = kt * kTile + lq * 4;
+        F8 dsf[RB][kNKF / 2];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+            for (int nf = 0; nf < kNKF; ++nf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float p = fast_exp2(fmaf(s[rb][nf][r], scale_log2e, -lse[rb]));
+                    if (ragged && key_base + nf * 16 + r >= Tk) p = 0.f;
+                    s[rb][nf][r] = p * (dp[rb][nf][r] - delta[rb]) * scale;
+                }
+#pragma unroll
+            for (int kk = 0; kk < kNKF / 2; ++kk) dsf[rb][kk] = pair_frag<T>(s[rb][2 * kk], s[rb][2 * kk + 1]);
+        }
+#pragma unroll
+        for (int df = 0; df < DF; ++df)
+#pragma unroll
+            for (int kk = 0; kk < kNKF / 2; ++kk) {
+                const F8 ktf = *reinterpret_cast<const F8*>(Ktc + (df * 16 + l15) * S::TROW + kk * 32 + lq * 8);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) acc[rb][df] = Mma<T>::k32(ktf, dsf[rb][kk], acc[rb][df]);
+            }
+        if (kt + 1 < n_tiles)
+            stage.store(Ks + (cur ^ 1) * S::K_HALFS, Vs + (cur ^ 1) * S::K_HALFS, Kt + (cur ^ 1) * S::V_HALFS);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int t = row0 + rb * 16 + l15;
+        if (t >= Tq) continue;
+        T* grow = dQ + ((int64_t)b * Tq + t) * HD + h * d;
+#pragma unroll
+        for (int df = 0; df < DF; ++df) {
+            const int c = df * 16 + lq * 4;
+            if (c < d) {
+                Quad4<T> out;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out.v[r] = from_f32<T>(acc[rb][df][r]);
+                *reinterpret_cast<Quad4<T>*>(grow + c) = out;
+            }
+        }
+    }
+}
+
+// one 64-row tile of Q and dO (row-major) plus LSE and Δ of those rows, global → registers → LDS
+template <typename T, int KS, int DF> struct QTileRegs {
+    using S = FlashShape<KS, DF>;
+    Chunk<T> q[S::IT], g[S::IT];
+    float lse, delta;  // threads 0..63 carry one row's statistics
+    __device__ __forceinline__ void load(const T* Qh, const T* Gh, const float* lse_h, const float* delta_h, int64_t HD,
+                                         int row0, int Tq, int d) {
+#pragma unroll
+        for (int i = 0; i < S::IT; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            const int row = idx / S::CPR, c = (idx - row * S::CPR) * 8;
+            const bool ok = idx < S::N && row0 + row < Tq && c < d;
+            const int64_t off = ok ? (int64_t)(row0 + row) * HD + c : 0;
+            q[i] = load_or_zero<T>(Qh + off, ok);
+            g[i] = load_or_zero<T>(Gh + off, ok);
+        }
+        const int r = row0 + (int)(threadIdx.x & 63);
+        const bool ok = r < Tq;
+        lse = ok ? lse_h[ok ? r : 0] : INFINITY;
+        delta = ok ? delta_h[ok ? r : 0] : 0.f;
+    }
+    __device__ __forceinline__ void store(T* Qs, T* Gs, float* lse_s, float* delta_s) const {
+#pragma unroll
+        for (int i = 0; i < S::IT; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            const int row = idx / S::CPR, c = (idx - row * S::CPR) * 8;
+            if (idx < S::N) {
+                *reinterpret_cast<Chunk<T>*>(Qs + row * S::KROW + c) = q[i];
+                *reinterpret_cast<Chunk<T>*>(Gs + row * S::KROW + c) = g[i];
+            }
+        }
+        if (threadIdx.x < 64) {
+            lse_s[threadIdx.x] = lse;
+            delta_s[threadIdx.x] = delta;
+        }
+    }
+};
+
+template <typename T, int KS, int DF, int NKW>
+__global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __restrict__ Q, const T* __restrict__ K,
+                                                               const T* __restrict__ V, const T* __restrict__ dO,
+                                                               const float* __restrict__ LSE,
+                                                               const float* __restrict__ Delta, T* __restrict__ dK,
+                                                               T* __restrict__ dV, int Tq, int Tk, int H, int d,
+                                                               float scale, float scale_log2e) {
+    using S = FlashShape<KS, DF>;
+    using F8 = typename Mma<T>::F8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Qs = reinterpret_cast<T*>(smem);          // [2][64][KROW]
+    T* Gs = Qs + 2 * S::K_HALFS;                  // [2][64][KROW]
+    float* lse_s = reinterpret_cast<float*>(Gs + 2 * S::K_HALFS);  // [2][64]
+    float* delta_s = lse_s + 2 * 64;                               // [2][64]
+
+    const int bh = blockIdx.y;
+    const int b = bh / H, h = bh - b * H;
+    const int64_t HD = (int64_t)H * d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const T* Qh = Q + (int64_t)b * Tq * HD + h * d;
+    const T* Gh = dO + (int64_t)b * Tq * HD + h * d;
+    const T* Kh = K + (int64_t)b * Tk * HD + h * d;
+    const T* Vh = V + (int64_t)b * Tk * HD + h * d;
+    const float* lse_h = LSE + (int64_t)bh * Tq;
+    const float* delta_h = Delta + (int64_t)bh * Tq;
+    const int key0 = blockIdx.x * (64 * NKW) + wave * (16 * NKW);  // first key of this wave
+
+    // the wave's keys as second MFMA operands (lane = key row, 8 head-dim values), kept for the whole kernel
+    F8 kfr[NKW][KS], vfr[NKW][KS];
+#pragma unroll
+    for (int nf = 0; nf < NKW; ++nf) {
+        const int key = key0 + nf * 16 + l15;
+        load_row_frags<T, KS>(Kh + (int64_t)key * HD, Kh, key < Tk, d, lq, kfr[nf]);
+        load_row_frags<T, KS>(Vh + (int64_t)key * HD, Vh, key < Tk, d, lq, vfr[nf]);
+    }
+    f32x4 dk[NKW][DF], dv[NKW][DF];  // lane = head-dim column l15 of fragment df; keys nf*16 + lq*4 + r
+#pragma unroll
+    for (int nf = 0; nf < NKW; ++nf)
+#pragma unroll
+        for (int df = 0; df < DF; ++df) dk[nf][df] = dv[nf][df] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    QTileRegs<T, KS, DF> stage;
+    stage.load(Qh, Gh, lse_h, delta_h, HD, 0, Tq, d);
+    stage.store(Qs, Gs, lse_s, delta_s);
+    __syncthreads();
+    const int n_tiles = (Tq + 63) / 64;
+    for (int qt = 0; qt < n_tiles; ++qt) {
+        const int cur = qt & 1;
+        const T* Qc = Qs + cur * S::K_HALFS;
+        const T* Gc = Gs + cur * S::K_HALFS;
+        const float* lc = lse_s + cur * 64;
+        const float* dc = delta_s + cur * 64;
+        if (qt + 1 < n_tiles) stage.load(Qh, Gh, lse_h, delta_h, HD, (qt + 1) * 64, Tq, d);
+#pragma unroll 1
+        for (int qb = 0; qb < 4; ++qb) {
+            F8 qa[KS], ga[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int off = (qb * 16 + l15) * S::KROW + ks * 32 + lq * 8;
+                qa[ks] = *reinterpret_cast<const F8*>(Qc + off);
+                ga[ks] = *reinterpret_cast<const F8*>(Gc + off);
+            }
+            const f32x4 lse4 = *reinterpret_cast<const f32x4*>(lc + qb * 16 + lq * 4);
+            const f32x4 del4 = *reinterpret_cast<const f32x4*>(dc + qb * 16 + lq * 4);
+            T qT[DF][4], gT[DF][4];  // transposed operands: lane = head-dim column, 4 query rows
+#pragma unroll
+            for (int df = 0; df < DF; ++df)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    qT[df][e] = Qc[(qb * 16 + lq * 4 + e) * S::KROW + df * 16 + l15];
+                    gT[df][e] = Gc[(qb * 16 + lq * 4 + e) * S::KROW + df * 16 + l15];
+                }
+#pragma unroll
+            for (int nf = 0; nf < NKW; ++nf) {
+                f32x4 s2 = f32x4{0.f, 0.f, 0.f, 0.f}, dp2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    s2 = Mma<T>::k32(qa[ks], kfr[nf][ks], s2);    // D[q][key]: lane = key, rows lq*4 + r
+                    dp2 = Mma<T>::k32(ga[ks], vfr[nf][ks], dp2);
+                }
+                const bool key_ok = key0 + nf * 16 + l15 < Tk;
+                T pa[4], dsa[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = key_ok ? fast_exp2(fmaf(s2[r], scale_log2e, -lse4[r])) : 0.f;
+                    pa[r] = from_f32<T>(p);
+                    dsa[r] = from_f32<T>(p * (dp2[r] - del4[r]) * scale);
+                }
+#pragma unroll
+                for (int df = 0; df < DF; ++df) {
+                    dv[nf][df] = Mma<T>::k16(pa, gT[df], dv[nf][df]);
+                    dk[nf][df] = Mma<T>::k16(dsa, qT[df], dk[nf][df]);
+                }
+            }
+        }
+        if (qt + 1 < n_tiles)
+            stage.store(Qs + (cur ^ 1) * S::K_HALFS, Gs + (cur ^ 1) * S::K_HALFS, lse_s + (cur ^ 1) * 64,
+                        delta_s + (cur ^ 1) * 64);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int nf = 0; nf < NKW; ++nf)
+#pragma unroll
+        for (int df = 0; df < DF; ++df) {
+            const int c = df * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = key0 + nf * 16 + lq * 4 + r;
+                if (key < Tk && c < d) {
+                    const int64_t off = ((int64_t)b * Tk + key) * HD + h * d + c;
+                    dK[off] = from_f32<T>(dk[nf][df][r]);
+                    dV[off] = from_f32<T>(dv[nf][df][r]);
+                }
+            }
+        }
+}
+
+struct FlashPlan {
+    int ks, df;
+    int rb;      // 16-row blocks per wave, forward
+    int rb_dq;   //                    ... dQ kernel (it carries dO fragments and dP accumulators as well)
+    int nkw;     // 16-key fragments per wave, dK/dV kernel
+};
+
+bool plan_flash(int B, int Tq, int Tk, int H, int d, FlashPlan* pl) {
+    if (B < 1 || Tq < 1 || Tk < 1 || H < 1 || d < 8 || (d % 8) != 0 || d > 160) return false;
+    if (d <= 48) { pl->ks = 2; pl->df = 3; pl->rb = 4; pl->rb_dq = 2; pl->nkw = 4; }
+    else if (d <= 64) { pl->ks = 2; pl->df = 4; pl->rb = 4; pl->rb_dq = 2; pl->nkw = 4; }
+    else if (d <= 80) { pl->ks = 3; pl->df = 5; pl->rb = 2; pl->rb_dq = 2; pl->nkw = 2; }
+    else if (d <= 96) { pl->ks = 3; pl->df = 6; pl->rb = 2; pl->rb_dq = 2; pl->nkw = 2; }
+    else if (d <= 128) { pl->ks = 4; pl->df = 8; pl->rb = 2; pl->rb_dq = 1; pl->nkw = 1; }
+    else { pl->ks = 5; pl->df = 10; pl->rb = 1; pl->rb_dq = 1; pl->nkw = 1; }
+    static const int rb_env = [] { const char* e = getenv("FLASH_RB"); return e ? atoi(e) : 0; }();
+    if (rb_env == 2 && pl->rb == 4) pl->rb = 2;  // tuning knob for tools/flash_check.py
+    return true;
+}
+
+template <int KS, int DF> constexpr int flash_fwd_lds() {
+    using S = FlashShape<KS, DF>;
+    return 2 * (S::K_HALFS + S::V_HALFS) * 2;
+}
+
+struct FlashArgs {
+    const void *Q, *K, *V;
+    void* O;
+    float* LSE;
+    int B, Tq, Tk, H, d;
+    float scale;
+};
+
+template <typename T, int KS, int DF, int RB>
+int launch_flash_fwd(const FlashArgs& a, hipStream_t stream) {
+    constexpr int lds = flash_fwd_lds<KS, DF>();
+    auto kern = attn_flash_fwd_kernel<T, KS, DF, RB>;
+    if (lds > 48 * 1024) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (attr != hipSuccess) return LORA_E_LAUNCH;
+    }
+    const dim3 grid((unsigned)((a.Tq + 64 * RB - 1) / (64 * RB)), (unsigned)(a.B * a.H));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, static_cast<const T*>(a.Q), static_cast<const T*>(a.K),
+                       static_cast<const T*>(a.V), static_cast<T*>(a.O), a.LSE, a.Tq, a.Tk, a.H, a.d,
+                       a.scale * 1.4426950408889634f);
+    LORA_LAUNCH_CHECK();
+    return LORA_OK;
+}
+
+template <typename T>
+int dispatch_flash_fwd(const FlashArgs& a, const FlashPlan& pl, hipStream_t stream) {
+#define FLASH_CASE(KS_, DF_, RB_) \
+    if (pl.ks == KS_ && pl.df == DF_ && pl.rb == RB_) return launch_flash_fwd<T, KS_, DF_, RB_>(a, stream);
+    FLASH_CASE(2, 3, 4) FLASH_CASE(2, 4, 4) FLASH_CASE(2, 3, 2) FLASH_CASE(2, 4, 2) FLASH_CASE(3, 5, 2) FLASH_CASE(3, 6, 2) FLASH_CASE(4, 8, 2) FLASH_CASE(5, 10, 1)
+#undef FLASH_CASE
+    return LORA_E_BADARG;
+}
+
+template <int KS, int DF> constexpr int flash_dq_lds() {
+    using S = FlashShape<KS, DF>;
+    return (4 * S::K_HALFS + 2 * S::V_HALFS) * 2;
+}
+template <int KS, int DF> constexpr int flash_dkdv_lds() {
+    using S = FlashShape<KS, DF>;
+    return 4 * S::K_HALFS * 2 + 4 * 64 * 4;
+}
+
+struct FlashBwdArgs {
+    const void *Q, *K, *V, *O, *dO;
+    const float* LSE;
+    void *dQ, *dK, *dV;
+    float* delta;
+    int B, Tq, Tk, H, d;
+    float scale;
+};
+
+template <typename T, int KS, int DF, int RBQ, int NKW>
+int launch_flash_bwd(const FlashBwdArgs& a, hipStream_t stream) {
+    const float l2e = a.scale * 1.4426950408889634f;
+    {
+        const int64_t rows = (int64_t)a.B * a.Tq * a.H;
+        const unsigned blocks = (unsigned)((rows + 255) / 256 > 4096 ? 4096 : (rows + 255) / 256);
+        hipLaunchKernelGGL(attn_flash_delta_kernel<T>, dim3(blocks), dim3(256), 0, stream, static_cast<const T*>(a.O),
+                           static_cast<const T*>(a.dO), a.delta, a.B, a.Tq, a.H, a.d);
+        LORA_LAUNCH_CHECK();
+    }
+    {
+        constexpr int lds = flash_dkdv_lds<KS, DF>();
+        auto kern = attn_flash_dkdv_kernel<T, KS, DF, NKW>;
+        if (lds > 48 * 1024) {
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (attr != hipSuccess) return LORA_E_LAUNCH;
+        }
+        const dim3 grid((unsigned)((a.Tk + 64 * NKW - 1) / (64 * NKW)), (unsigned)(a.B * a.H));
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, static_cast<const T*>(a.Q), static_cast<const T*>(a.K),
+                           static_cast<const T*>(a.V), static_cast<const T*>(a.dO), a.LSE, a.delta,
+                           static_cast<T*>(a.dK), static_cast<T*>(a.dV), a.Tq, a.Tk, a.H, a.d, a.scale, l2e);
+        LORA_LAUNCH_CHECK();
+    }
+    {
+        constexpr int lds = flash_dq_lds<KS, DF>();
+        auto kern = attn_flash_dq_kernel<T, KS, DF, RBQ>;
+        if (lds > 48 * 1024) {
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (attr != hipSuccess) return LORA_E_LAUNCH;
+        }
+        const dim3 grid((unsigned)((a.Tq + 64 * RBQ - 1) / (64 * RBQ)), (unsigned)(a.B * a.H));
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, static_cast<const T*>(a.Q), static_cast<const T*>(a.K),
+                           static_cast<const T*>(a.V), static_cast<const T*>(a.dO), a.LSE, a.delta,
+                           static_cast<T*>(a.dQ), a.Tq, a.Tk, a.H, a.d, a.scale, l2e);
+        LORA_LAUNCH_CHECK();
+    }
+    return LORA_OK;
+}
+
+template <typename T>
+int dispatch_flash_bwd(const FlashBwdArgs& a, const FlashPlan& pl, hipStream_t stream) {
+#define FLASH_BCASE(KS_, DF_, RBQ_, NKW_) \
+    if (pl.ks == KS_ && pl.df == DF_) return launch_flash_bwd<T, KS_, DF_, RBQ_, NKW_>(a, stream);
+    FLASH_BCASE(2, 3, 2, 4) FLASH_BCASE(2, 4, 2, 4) FLASH_BCASE(3, 5, 2, 2) FLASH_BCASE(3, 6, 2, 2)
+    FLASH_BCASE(4, 8, 1, 1) FLASH_BCASE(5, 10, 1, 1)
+#undef FLASH_BCASE
+    return LORA_E_BADARG;
+}
+
+}  // namespace
+
+extern "C" int64_t attn_flash_bwd_workspace_bytes(int B, int Tq, int H) { return (int64_t)B * H * Tq * 4; }
+
+extern "C" int attn_flash_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                              const float* LSE, void* dQ, void* dK, void* dV, void* workspace, int B, int Tq, int Tk,
+                              int H, int d, float scale, int dtype, void* stream) {
+    if (!Q || !K || !V || !O || !dO || !LSE || !dQ || !dK || !dV || !workspace) return LORA_E_BADARG;
+    if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || !aligned16(O) || !aligned16(dO) || !aligned16(dQ) ||
+        !aligned16(workspace))
+        return LORA_E_BADARG;
+    FlashPlan pl;
+    if (!plan_flash(B, Tq, Tk, H, d, &pl)) return LORA_E_BADARG;
+    FlashBwdArgs a{Q, K, V, O, dO, LSE, dQ, dK, dV, static_cast<float*>(workspace), B, Tq, Tk, H, d, scale};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case LORA_F16: return dispatch_flash_bwd<half_t>(a, pl, s);
+        case LORA_BF16: return dispatch_flash_bwd<bf16_t>(a, pl, s);
+        default: return LORA_E_BADARG;
+    }
+}
+
+extern "C" int attn_flash_supported(int B, int Tq, int Tk, int H, int d, int dtype) {
+    FlashPlan pl;
+    return (dtype == LORA_F16 || dtype == LORA_BF16) && plan_flash(B, Tq, Tk, H, d, &pl) ? 1 : 0;
+}
+
+extern "C" int attn_flash_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int Tq, int Tk,
+                              int H, int d, float scale, int dtype, void* stream) {
+    if (!Q || !K || !V || !O) return LORA_E_BADARG;
+    if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || !aligned16(O)) return LORA_E_BADARG;
+    FlashPlan pl;
+    if (!plan_flash(B, Tq, Tk, H, d, &pl)) return LORA_E_BADARG;
+    FlashArgs a{Q, K, V, O, LSE, B, Tq, Tk, H, d, scale};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case LORA_F16: return dispatch_flash_fwd<half_t>(a, pl, s);
+        case LORA_BF16: return dispatch_flash_fwd<bf16_t>(a, pl, s);
+        default: return LORA_E_BADARG;
+    }
+}

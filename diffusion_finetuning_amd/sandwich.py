@@ -1,5 +1,6 @@
-"""Autograd fronts of the ops sandwiched by the hot path in a transformer block: the GEGLU gate,
-the short-context (cross-) attention core, and the head split/merge around the long-context attention core.
+"""Autograd fronts of the ops sandwiched by the hot path in a transformer block: the GEGLU gate, the
+short-context (cross-) and long-context (self-) attention cores, and the head split/merge for callers that keep their
+own attention kernel.
 HIP device only, like the rest of the path."""
 import torch
 from torch.autograd.function import once_differentiable
@@ -100,3 +101,40 @@ def ctx_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
     if scale is None:
         scale = (q.shape[-1] // heads) ** -0.5
     return _CtxAttentionFn.apply(q, k, v, heads, float(scale))
+
+
+class _FlashAttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, heads, scale):
+        q, k, v = (t if t.is_contiguous() else t.contiguous() for t in (q, k, v))
+        need = any(ctx.needs_input_grad[:3])
+        out, lse = nat.attn_flash_fwd(q, k, v, heads, scale, want_lse=need)
+        if need:
+            ctx.save_for_backward(q, k, v, out, lse)
+        ctx.heads, ctx.scale = heads, scale
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        dq, dk, dv = nat.attn_flash_bwd(q, k, v, out, dout if dout.is_contiguous() else dout.contiguous(), lse,
+                                        ctx.heads, ctx.scale)
+        return dq, dk, dv, None, None
+
+
+def flash_attention_supported(q: torch.Tensor, k: torch.Tensor, heads: int) -> bool:
+    """True when `flash_attention` handles these tensors (f16/bf16 on the HIP device, head dim ≤ 160, any lengths)."""
+    if not q.is_cuda or q.dim() != 3 or k.dim() != 3 or q.shape[-1] % heads:
+        return False
+    return nat.attn_flash_supported(q.shape[0], q.shape[1], k.shape[1], heads, q.shape[-1] // heads, q.dtype)
+
+
+def flash_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float = None) -> torch.Tensor:
+    """softmax(q·kᵀ·scale)·v per head for key/value sequences of any length (online softmax over key tiles; nothing of
+    size Tq×Tk is ever stored).  Same [B,T,H·d] layouts as `ctx_attention`, which is the faster choice up to 128 keys."""
+    if not q.is_cuda:
+        raise RuntimeError("flash_attention runs only on a HIP device; there is no CPU fallback")
+    if scale is None:
+        scale = (q.shape[-1] // heads) ** -0.5
+    return _FlashAttentionFn.apply(q, k, v, heads, float(scale))

@@ -231,6 +231,24 @@ int attn_ctx_bwd(const void* Q, const void* K, const void* V, const void* dO, vo
                  void* workspace, int B, int Tq, int Tk, int H, int d, float scale, int dtype, void* stream);
 
 /*
+ * Long-context attention core (self-attention: thousands of keys), same tensor layouts as attn_ctx_*: flash-style
+ * online softmax over 64-key tiles, no [Tq, Tk] matrix in memory.
+ *   attn_flash_supported          : 1 for f16/bf16, d % 8 == 0, d <= 160.
+ *   attn_flash_fwd                : O and LSE [B, H, Tq] fp32 = log2-sum-exp2 of the scaled scores (saved for backward;
+ *                                   may be NULL when no backward follows).
+ *   attn_flash_bwd_workspace_bytes: B·H·Tq·4 (the softmax correction Δ = Σ dO·O per query row).
+ *   attn_flash_bwd                : dQ, dK, dV from Q, K, V, O, dO, LSE.  Three launches (Δ; key-owned dK/dV; query-owned
+ *                                   dQ), every output element written by one workgroup: deterministic, no atomics.
+ */
+int attn_flash_supported(int B, int Tq, int Tk, int H, int d, int dtype);
+int attn_flash_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int Tq, int Tk, int H,
+                   int d, float scale, int dtype, void* stream);
+int64_t attn_flash_bwd_workspace_bytes(int B, int Tq, int H);
+int attn_flash_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+                   void* dQ, void* dK, void* dV, void* workspace, int B, int Tq, int Tk, int H, int d, float scale,
+                   int dtype, void* stream);
+
+/*
  * Launch profiler (measurement only; off by default).  When enabled, the hot-path kernels are launched
  * with start/stop events attached to the dispatch itself, so each record is that kernel's own duration on
  * the caller's stream, together with the ALGORITHMIC bytes and flops of the call (formulas: DESIGN.md §5).

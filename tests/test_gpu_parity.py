@@ -835,6 +835,59 @@ def test_ctx_attention_core_against_float64_reference(relerr, dtype):
             assert relerr(a, b) < tol, (name, (B, Tq, Tk, H, d), relerr(a, b))
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_flash_attention_core_against_float64_reference(relerr, dtype):
+    """f-4 (third part): the long-context attention kernels (online softmax over 64-key tiles; forward, dQ, dK, dV) on the
+    SD self-attention shapes (4096 tokens × heads of 40, 1024 × 80, 256 × 160), ragged query/key counts, cross shapes with
+    more than 128 keys and every head-dim bucket — against float64 math on the same 16-bit inputs."""
+    from diffusion_finetuning_amd.sandwich import flash_attention, flash_attention_supported
+
+    tol = 2e-3 if dtype == torch.float16 else 1.2e-2
+    g = torch.Generator().manual_seed(31)
+    shapes = [(1, 64, 64, 1, 40), (2, 200, 130, 2, 40), (1, 256, 256, 2, 64), (2, 1024, 1024, 4, 80), (1, 256, 256, 8, 160),
+              (1, 70, 300, 2, 96), (1, 100, 77, 2, 128), (1, 1, 1, 1, 8), (1, 333, 65, 3, 48), (1, 4096, 4096, 4, 40)]
+    for (B, Tq, Tk, H, d) in shapes:
+        q = torch.randn(B, Tq, H * d, generator=g).to(dtype)
+        k = torch.randn(B, Tk, H * d, generator=g).to(dtype)
+        v = torch.randn(B, Tk, H * d, generator=g).to(dtype)
+        go = torch.randn(B, Tq, H * d, generator=g).to(dtype)
+        qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
+        want = _attention_reference(qr, kr, vr, H)
+        want.backward(go.double())
+        qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+        assert flash_attention_supported(qd, kd, H)
+        got = flash_attention(qd, kd, vd, H)
+        got.backward(go.to(DEV))
+        for name, a, b in (("o", got, want), ("dq", qd.grad, qr.grad), ("dk", kd.grad, kr.grad), ("dv", vd.grad, vr.grad)):
+            assert relerr(a, b) < tol, (name, (B, Tq, Tk, H, d), relerr(a, b))
+    # inference form (no gradient requested): no log-sum-exp buffer, same output
+    with torch.no_grad():
+        assert torch.equal(flash_attention(qd, kd, vd, H), got)
+
+
+def test_flash_attention_is_deterministic_and_bounded():
+    from diffusion_finetuning_amd.sandwich import flash_attention, flash_attention_supported
+
+    g = torch.Generator().manual_seed(32)
+    q = torch.randn(2, 1024, 640, generator=g).half().to(DEV).requires_grad_(True)
+    k = torch.randn(2, 1024, 640, generator=g).half().to(DEV).requires_grad_(True)
+    v = torch.randn(2, 1024, 640, generator=g).half().to(DEV).requires_grad_(True)
+    go = torch.randn(2, 1024, 640, generator=g).half().to(DEV)
+    runs = []
+    for _ in range(2):
+        o = flash_attention(q, k, v, 8)
+        runs.append((o.detach().clone(),) + tuple(t.clone() for t in torch.autograd.grad(o, (q, k, v), go)))
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)  # every output element has one owner: bit-identical from run to run
+    assert not flash_attention_supported(q.float(), k.float(), 8)
+    assert not flash_attention_supported(q, k, 2)  # head dim 320
+    # large scores: the running maximum keeps exp2 in range (no inf/nan), rows still sum to one
+    big = (torch.randn(1, 128, 64, generator=g) * 30).half().to(DEV)
+    ones = torch.ones(1, 128, 64, dtype=torch.float16, device=DEV)
+    out = flash_attention(big, big, ones, 1)
+    assert torch.isfinite(out).all() and (out - 1).abs().max() < 2e-3
+
+
 def test_ctx_attention_is_deterministic_and_rejects_what_it_does_not_cover():
     from diffusion_finetuning_amd.sandwich import ctx_attention, ctx_attention_supported
 
@@ -859,8 +912,9 @@ def test_ctx_attention_is_deterministic_and_rejects_what_it_does_not_cover():
 
 def test_attention_hook_routes_cross_attention_through_the_hip_core(relerr):
     """`set_use_memory_efficient_attention_xformers(model, True)` — the reference's own switch
-    (lora_diffusion/xformers_utils.py:41-70) — sends the cross-attention of a transformer block through ctx_attention
-    and leaves self-attention to the module; output and LoRA gradients agree with the un-hooked block; `False` undoes it."""
+    (lora_diffusion/xformers_utils.py:41-70) — sends both attentions of a transformer block through the HIP cores
+    (self-attention: flash_attention, cross-attention: ctx_attention); output and LoRA gradients agree with the un-hooked
+    block; `False` undoes it."""
     import harness.unet as hu
     from diffusion_finetuning_amd import attention, sandwich
     from lora_diffusion.xformers_utils import set_use_memory_efficient_attention_xformers as hook
@@ -886,15 +940,16 @@ def test_attention_hook_routes_cross_attention_through_the_hip_core(relerr):
 
     ref, ref_grads = run()
     calls = []
-    real = attention.ctx_attention
-    attention.ctx_attention = lambda *a, **kw: (calls.append(1), real(*a, **kw))[1]
+    real, real_flash = attention.ctx_attention, attention.flash_attention
+    attention.ctx_attention = lambda *a, **kw: (calls.append("ctx"), real(*a, **kw))[1]
+    attention.flash_attention = lambda *a, **kw: (calls.append("flash"), real_flash(*a, **kw))[1]
     try:
         hook(blk, True)
         hook(blk, True)  # idempotent
         out, grads = run()
     finally:
-        attention.ctx_attention = real
-    assert len(calls) == 1  # attn2 only: attn1 has no context and 256 keys, it went to the module's own forward
+        attention.ctx_attention, attention.flash_attention = real, real_flash
+    assert calls == ["flash", "ctx"]  # attn1: 256 keys → tiled kernel; attn2: 77 text tokens → single-tile kernel
     assert relerr(out, ref) < 2e-3
     for a, b in zip(grads, ref_grads):
         assert relerr(a, b) < 2e-2
