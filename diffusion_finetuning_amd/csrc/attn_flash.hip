@@ -10,6 +10,7 @@
 // rescaling, several 16-row blocks per wave so that every K / V fragment read from LDS is used RB times, and the
 // row-wise log-sum-exp (base 2, of the scaled scores) written out for the backward kernels.
 #include <cstdlib>
+#include <type_traits>
 
 #include "attn_common.h"
 
@@ -107,7 +108,9 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restr
     stage.store(Ks, Vt);
     __syncthreads();
     const int n_tiles = (Tk + kTile - 1) / kTile;
-    for (int kt = 0; kt < n_tiles; ++kt) {
+    // one key tile; RAGGED (only ever the last tile) is a compile-time flag so that full tiles carry no masking code
+    auto tile = [&](int kt, auto ragged_tag) {
+        constexpr bool RAGGED = decltype(ragged_tag)::value;
         const int cur = kt & 1;
         const T* Kc = Ks + cur * S::K_HALFS;
         const T* Vc = Vt + cur * S::V_HALFS;
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restr
                 for (int rb = 0; rb < RB; ++rb) s[rb][nf] = Mma<T>::k32(kf, qf[rb][ks], s[rb][nf]);
             }
         // ---- online softmax, one query row per lane (raw scores stay unscaled: exp2(s·c − m) is one fma + v_exp) ----
-        if ((kt + 1) * kTile > Tk) {  // the ragged last tile: keys past Tk never win the max and get probability 0
+        if constexpr (RAGGED) {  // keys past Tk never win the max and get probability 0
             const int key_base = kt * kTile + lq * 4;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
@@ -179,7 +182,10 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restr
             }
         if (kt + 1 < n_tiles) stage.store(Ks + (cur ^ 1) * S::K_HALFS, Vt + (cur ^ 1) * S::V_HALFS);
         __syncthreads();
-    }
+    };
+    const int n_full = Tk / kTile;
+    for (int kt = 0; kt < n_full; ++kt) tile(kt, std::false_type{});
+    if (n_full < n_tiles) tile(n_full, std::true_type{});
 
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
@@ -308,7 +314,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const T* __restri
     stage.store(Ks, Vs, Kt);
     __syncthreads();
     const int n_tiles = (Tk + kTile - 1) / kTile;
-    for (int kt = 0; kt < n_tiles; ++kt) {
+    auto tile = [&](int kt, auto ragged_tag) {
+        constexpr bool RAGGED = decltype(ragged_tag)::value;
         const int cur = kt & 1;
         const T* Kc = Ks + cur * S::K_HALFS;
         const T* Vc = Vs + cur * S::K_HALFS;
@@ -333,7 +340,6 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const T* __restri
                     dp[rb][nf] = Mma<T>::k32(vf, gf[rb][ks], dp[rb][nf]);
                 }
             }
-        const bool ragged = (kt + 1) * kTile > Tk;
         const int key_base = kt * kTile + lq * 4;
         F8 dsf[RB][kNKF / 2];
 #pragma unroll
@@ -343,8 +349,10 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const T* __restri
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float p = fast_exp2(fmaf(s[rb][nf][r], scale_log2e, -lse[rb]));
-                    if (ragged && key_base + nf * 16 + r >= Tk) p = 0.f;
-                    s[rb][nf][r] = p * (dp[rb][nf][r] - delta[rb]) * scale;
+                    if constexpr (RAGGED) {
+                        if (key_base + nf * 16 + r >= Tk) p = 0.f;
+                    }
+                    s[rb][nf][r] = p * (dp[rb][nf][r] - delta[rb]);  // the 1/√d factor is applied once, on the way out
                 }
 #pragma unroll
             for (int kk = 0; kk < kNKF / 2; ++kk) dsf[rb][kk] = pair_frag<T>(s[rb][2 * kk], s[rb][2 * kk + 1]);
@@ -360,7 +368,10 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const T* __restri
         if (kt + 1 < n_tiles)
             stage.store(Ks + (cur ^ 1) * S::K_HALFS, Vs + (cur ^ 1) * S::K_HALFS, Kt + (cur ^ 1) * S::V_HALFS);
         __syncthreads();
-    }
+    };
+    const int n_full = Tk / kTile;
+    for (int kt = 0; kt < n_full; ++kt) tile(kt, std::false_type{});
+    if (n_full < n_tiles) tile(n_full, std::true_type{});
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
         const int t = row0 + rb * 16 + l15;
@@ -372,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const T* __restri
             if (c < d) {
                 Quad4<T> out;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) out.v[r] = from_f32<T>(acc[rb][df][r]);
+                for (int r = 0; r < 4; ++r) out.v[r] = from_f32<T>(acc[rb][df][r] * scale);
                 *reinterpret_cast<Quad4<T>*>(grow + c) = out;
             }
         }
@@ -417,7 +428,10 @@ template <typename T, int KS, int DF> struct QTileRegs {
     }
 };
 
-template <typename T, int KS, int DF, int NKW>
+// PAIR: contract over two 16-row query blocks per MFMA (16x16x32) instead of one (16x16x16).  Half the MFMA issues for
+// dK/dV, but two blocks of operands live at once: a win for wide heads (few key fragments per wave), a loss for the
+// 40/64-wide heads where four key fragments per wave already fill the register file (measured: tools/flash_check.py).
+template <typename T, int KS, int DF, int NKW, bool PAIR>
 __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __restrict__ Q, const T* __restrict__ K,
                                                                const T* __restrict__ V, const T* __restrict__ dO,
                                                                const float* __restrict__ LSE,
@@ -471,45 +485,98 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
         const float* lc = lse_s + cur * 64;
         const float* dc = delta_s + cur * 64;
         if (qt + 1 < n_tiles) stage.load(Qh, Gh, lse_h, delta_h, HD, (qt + 1) * 64, Tq, d);
+        const bool keys_ragged = key0 + 16 * NKW > Tk;  // wave-uniform: only the last wave of the last workgroup
+        if constexpr (PAIR) {
 #pragma unroll 1
-        for (int qb = 0; qb < 4; ++qb) {
-            F8 qa[KS], ga[KS];
+            for (int qg = 0; qg < 2; ++qg) {  // 32 query rows at a time: two 16-row blocks fill one 32-deep MFMA contraction
+                const int r0 = qg * 32;
+                F8 pa[NKW], dsa[NKW];  // rows = the wave's keys (lane l15); contraction slot (lq, e) = row hb*16 + lq*4 + (e & 3)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int off = (qb * 16 + l15) * S::KROW + ks * 32 + lq * 8;
-                qa[ks] = *reinterpret_cast<const F8*>(Qc + off);
-                ga[ks] = *reinterpret_cast<const F8*>(Gc + off);
-            }
-            const f32x4 lse4 = *reinterpret_cast<const f32x4*>(lc + qb * 16 + lq * 4);
-            const f32x4 del4 = *reinterpret_cast<const f32x4*>(dc + qb * 16 + lq * 4);
-            T qT[DF][4], gT[DF][4];  // transposed operands: lane = head-dim column, 4 query rows
+                for (int hb = 0; hb < 2; ++hb) {
+                    F8 qa[KS], ga[KS];
 #pragma unroll
-            for (int df = 0; df < DF; ++df)
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const int off = (r0 + hb * 16 + l15) * S::KROW + ks * 32 + lq * 8;
+                        qa[ks] = *reinterpret_cast<const F8*>(Qc + off);
+                        ga[ks] = *reinterpret_cast<const F8*>(Gc + off);
+                    }
+                    const f32x4 lse4 = *reinterpret_cast<const f32x4*>(lc + r0 + hb * 16 + lq * 4);
+                    const f32x4 del4 = *reinterpret_cast<const f32x4*>(dc + r0 + hb * 16 + lq * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    qT[df][e] = Qc[(qb * 16 + lq * 4 + e) * S::KROW + df * 16 + l15];
-                    gT[df][e] = Gc[(qb * 16 + lq * 4 + e) * S::KROW + df * 16 + l15];
+                    for (int nf = 0; nf < NKW; ++nf) {
+                        f32x4 s2 = f32x4{0.f, 0.f, 0.f, 0.f}, dp2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            s2 = Mma<T>::k32(qa[ks], kfr[nf][ks], s2);  // D[q][key]: lane = key, rows lq*4 + r
+                            dp2 = Mma<T>::k32(ga[ks], vfr[nf][ks], dp2);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float p = fast_exp2(fmaf(s2[r], scale_log2e, -lse4[r]));
+                            if (keys_ragged && key0 + nf * 16 + l15 >= Tk) p = 0.f;
+                            pa[nf][hb * 4 + r] = from_f32<T>(p);
+                            dsa[nf][hb * 4 + r] = from_f32<T>(p * (dp2[r] - del4[r]));  // 1/√d goes onto dK at the end
+                        }
+                    }
                 }
-#pragma unroll
-            for (int nf = 0; nf < NKW; ++nf) {
-                f32x4 s2 = f32x4{0.f, 0.f, 0.f, 0.f}, dp2 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    s2 = Mma<T>::k32(qa[ks], kfr[nf][ks], s2);    // D[q][key]: lane = key, rows lq*4 + r
-                    dp2 = Mma<T>::k32(ga[ks], vfr[nf][ks], dp2);
-                }
-                const bool key_ok = key0 + nf * 16 + l15 < Tk;
-                T pa[4], dsa[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = key_ok ? fast_exp2(fmaf(s2[r], scale_log2e, -lse4[r])) : 0.f;
-                    pa[r] = from_f32<T>(p);
-                    dsa[r] = from_f32<T>(p * (dp2[r] - del4[r]) * scale);
-                }
+                // transposed operands (lane = head-dim column, same contraction slots), one fragment at a time
 #pragma unroll
                 for (int df = 0; df < DF; ++df) {
-                    dv[nf][df] = Mma<T>::k16(pa, gT[df], dv[nf][df]);
-                    dk[nf][df] = Mma<T>::k16(dsa, qT[df], dk[nf][df]);
+                    F8 qT, gT;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int row = r0 + (e >> 2) * 16 + lq * 4 + (e & 3);
+                        qT[e] = Qc[row * S::KROW + df * 16 + l15];
+                        gT[e] = Gc[row * S::KROW + df * 16 + l15];
+                    }
+#pragma unroll
+                    for (int nf = 0; nf < NKW; ++nf) {
+                        dv[nf][df] = Mma<T>::k32(pa[nf], gT, dv[nf][df]);
+                        dk[nf][df] = Mma<T>::k32(dsa[nf], qT, dk[nf][df]);
+                    }
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int qb = 0; qb < 4; ++qb) {
+                F8 qa[KS], ga[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int off = (qb * 16 + l15) * S::KROW + ks * 32 + lq * 8;
+                    qa[ks] = *reinterpret_cast<const F8*>(Qc + off);
+                    ga[ks] = *reinterpret_cast<const F8*>(Gc + off);
+                }
+                const f32x4 lse4 = *reinterpret_cast<const f32x4*>(lc + qb * 16 + lq * 4);
+                const f32x4 del4 = *reinterpret_cast<const f32x4*>(dc + qb * 16 + lq * 4);
+                T qT[DF][4], gT[DF][4];  // transposed operands: lane = head-dim column, 4 query rows
+#pragma unroll
+                for (int df = 0; df < DF; ++df)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        qT[df][e] = Qc[(qb * 16 + lq * 4 + e) * S::KROW + df * 16 + l15];
+                        gT[df][e] = Gc[(qb * 16 + lq * 4 + e) * S::KROW + df * 16 + l15];
+                    }
+#pragma unroll
+                for (int nf = 0; nf < NKW; ++nf) {
+                    f32x4 s2 = f32x4{0.f, 0.f, 0.f, 0.f}, dp2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        s2 = Mma<T>::k32(qa[ks], kfr[nf][ks], s2);    // D[q][key]: lane = key, rows lq*4 + r
+                        dp2 = Mma<T>::k32(ga[ks], vfr[nf][ks], dp2);
+                    }
+                    T pa[4], dsa[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float p = fast_exp2(fmaf(s2[r], scale_log2e, -lse4[r]));
+                        if (keys_ragged && key0 + nf * 16 + l15 >= Tk) p = 0.f;
+                        pa[r] = from_f32<T>(p);
+                        dsa[r] = from_f32<T>(p * (dp2[r] - del4[r]));  // 1/√d goes onto dK at the end
+                    }
+#pragma unroll
+                    for (int df = 0; df < DF; ++df) {
+                        dv[nf][df] = Mma<T>::k16(pa, gT[df], dv[nf][df]);
+                        dk[nf][df] = Mma<T>::k16(dsa, qT[df], dk[nf][df]);
+                    }
                 }
             }
         }
@@ -528,7 +595,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
                 const int key = key0 + nf * 16 + lq * 4 + r;
                 if (key < Tk && c < d) {
                     const int64_t off = ((int64_t)b * Tk + key) * HD + h * d + c;
-                    dK[off] = from_f32<T>(dk[nf][df][r]);
+                    dK[off] = from_f32<T>(dk[nf][df][r] * scale);
                     dV[off] = from_f32<T>(dv[nf][df][r]);
                 }
             }
@@ -624,7 +691,7 @@ int launch_flash_bwd(const FlashBwdArgs& a, hipStream_t stream) {
     }
     {
         constexpr int lds = flash_dkdv_lds<KS, DF>();
-        auto kern = attn_flash_dkdv_kernel<T, KS, DF, NKW>;
+        auto kern = attn_flash_dkdv_kernel<T, KS, DF, NKW, (KS >= 3)>;
         if (lds > 48 * 1024) {
             static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -656,7 +723,7 @@ int launch_flash_bwd(const FlashBwdArgs& a, hipStream_t stream) {
 template <typename T>
 int dispatch_flash_bwd(const FlashBwdArgs& a, const FlashPlan& pl, hipStream_t stream) {
 #define FLASH_BCASE(KS_, DF_, RBQ_, NKW_) \
-    if (pl.ks == KS_ && pl.df == DF_) return launch_flash_bwd<T, KS_, DF_, RBQ_, NKW_>(a, stream);
+    if (pl.ks == KS_ && pl.df == DF_ && pl.nkw == NKW_) return launch_flash_bwd<T, KS_, DF_, RBQ_, NKW_>(a, stream);
     FLASH_BCASE(2, 3, 2, 4) FLASH_BCASE(2, 4, 2, 4) FLASH_BCASE(3, 5, 2, 2) FLASH_BCASE(3, 6, 2, 2)
     FLASH_BCASE(4, 8, 1, 1) FLASH_BCASE(5, 10, 1, 1)
 #undef FLASH_BCASE
