@@ -31,37 +31,88 @@ template <int KS, int DF> struct FlashShape {
     static constexpr int V_HALFS = DV * TROW;
 };
 
-// one 64-key tile of K and V on its way global → registers → LDS
-template <typename T, int KS, int DF> struct TileRegs {
+template <int KS, int DF> constexpr int flash_fwd_lds_bytes() {
+    return 2 * (FlashShape<KS, DF>::K_HALFS + FlashShape<KS, DF>::V_HALFS) * 2;
+}
+template <int KS, int DF> constexpr int flash_dq_lds_bytes() {
+    return (4 * FlashShape<KS, DF>::K_HALFS + 2 * FlashShape<KS, DF>::V_HALFS) * 2;
+}
+template <int KS, int DF> constexpr int flash_dkdv_lds_bytes() { return 4 * FlashShape<KS, DF>::K_HALFS * 2 + 4 * 64 * 4; }
+
+// One 64-row tile of two [rows, H·d] tensors (K and V, or Q and dO) on its way global → registers → LDS.
+// The chunk map is fixed for the whole kernel and computed once: a thread owns up to IT 16-byte chunks (row, col) of
+// the d/8 REAL chunks of each row — the padding columns of the LDS tiles are zeroed once, never re-staged — so a full
+// tile costs one 64-bit add and two unpredicated loads per chunk, no selects; only a ragged last tile checks rows.
+template <typename T, int KS, int DF> struct TileStage {
     using S = FlashShape<KS, DF>;
-    Chunk<T> k[S::IT], v[S::IT];
-    __device__ __forceinline__ void load(const T* Kh, const T* Vh, int64_t HD, int key0, int Tk, int d) {
+    Chunk<T> a[S::IT], b[S::IT];
+    int64_t src[S::IT];           // element offset of the chunk inside tile 0
+    int row[S::IT], rowoff[S::IT], troff[S::IT];  // row; offset in a row-major [64][KROW] tile; in a transposed [DV][TROW] one
+    bool have[S::IT];
+    __device__ __forceinline__ void init(int d, int64_t ld) {
+        const int cpr = d >> 3, n = kTile * cpr;
 #pragma unroll
         for (int i = 0; i < S::IT; ++i) {
             const int idx = threadIdx.x + i * 256;
-            const int key = idx / S::CPR, c = (idx - key * S::CPR) * 8;
-            const bool ok = idx < S::N && key0 + key < Tk && c < d;
-            const int64_t off = ok ? (int64_t)(key0 + key) * HD + c : 0;
-            k[i] = load_or_zero<T>(Kh + off, ok);
-            v[i] = load_or_zero<T>(Vh + off, ok);
+            have[i] = idx < n;
+            const int r = have[i] ? idx / cpr : 0, c = have[i] ? (idx - r * cpr) * 8 : 0;
+            row[i] = r;
+            src[i] = (int64_t)r * ld + c;
+            rowoff[i] = r * S::KROW + c;
+            troff[i] = c * S::TROW + key_pos(r);
         }
     }
-    __device__ __forceinline__ void store(T* Ks, T* Vt) const {
+    // tile_off = first row of the tile × row stride; rows_valid >= 64 for a full tile
+    __device__ __forceinline__ void load(const T* A, const T* B, int64_t tile_off, int rows_valid) {
+        if (rows_valid >= kTile) {
 #pragma unroll
-        for (int i = 0; i < S::IT; ++i) {
-            const int idx = threadIdx.x + i * 256;
-            const int key = idx / S::CPR, c = (idx - key * S::CPR) * 8;
-            if (idx < S::N) {
-                *reinterpret_cast<Chunk<T>*>(Ks + key * S::KROW + c) = k[i];
-                if (c < S::DV) {
-                    const int pos = key_pos(key);
+            for (int i = 0; i < S::IT; ++i) {
+                const int64_t off = have[i] ? src[i] + tile_off : 0;
+                a[i] = *reinterpret_cast<const Chunk<T>*>(A + off);
+                b[i] = *reinterpret_cast<const Chunk<T>*>(B + off);
+            }
+        } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) Vt[(c + e) * S::TROW + pos] = v[i].v[e];
-                }
+            for (int i = 0; i < S::IT; ++i) {
+                const bool ok = have[i] && row[i] < rows_valid;
+                const int64_t off = ok ? src[i] + tile_off : 0;
+                a[i] = load_or_zero<T>(A + off, ok);
+                b[i] = load_or_zero<T>(B + off, ok);
             }
         }
     }
+    __device__ __forceinline__ void store_a_rows(T* dst) const {
+#pragma unroll
+        for (int i = 0; i < S::IT; ++i)
+            if (have[i]) *reinterpret_cast<Chunk<T>*>(dst + rowoff[i]) = a[i];
+    }
+    __device__ __forceinline__ void store_b_rows(T* dst) const {
+#pragma unroll
+        for (int i = 0; i < S::IT; ++i)
+            if (have[i]) *reinterpret_cast<Chunk<T>*>(dst + rowoff[i]) = b[i];
+    }
+    __device__ __forceinline__ void store_a_transposed(T* dst) const {
+#pragma unroll
+        for (int i = 0; i < S::IT; ++i)
+            if (have[i]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dst[troff[i] + e * S::TROW] = a[i].v[e];
+            }
+    }
+    __device__ __forceinline__ void store_b_transposed(T* dst) const {
+#pragma unroll
+        for (int i = 0; i < S::IT; ++i)
+            if (have[i]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dst[troff[i] + e * S::TROW] = b[i].v[e];
+            }
+    }
 };
+
+// zero `bytes` of LDS (multiple of 16) cooperatively: the padding columns / rows of the tiles stay zero for the kernel's life
+__device__ __forceinline__ void lds_zero(char* base, int bytes) {
+    for (int o = threadIdx.x * 16; o < bytes; o += 256 * 16) *reinterpret_cast<f32x4*>(base + o) = f32x4{0.f, 0.f, 0.f, 0.f};
+}
 
 // v_exp_f32 without the library's denormal-range fix-ups (arguments here are <= 0; tiny results may flush to zero)
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -103,9 +154,13 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restr
         for (int df = 0; df < DF; ++df) o[rb][df] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    TileRegs<T, KS, DF> stage;
-    stage.load(Kh, Vh, HD, 0, Tk, d);
-    stage.store(Ks, Vt);
+    lds_zero(smem, flash_fwd_lds_bytes<KS, DF>());
+    __syncthreads();
+    TileStage<T, KS, DF> stage;
+    stage.init(d, HD);
+    stage.load(Kh, Vh, 0, Tk);
+    stage.store_a_rows(Ks);
+    stage.store_b_transposed(Vt);
     __syncthreads();
     const int n_tiles = (Tk + kTile - 1) / kTile;
     // one key tile; RAGGED (only ever the last tile) is a compile-time flag so that full tiles carry no masking code
@@ -114,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restr
         const int cur = kt & 1;
         const T* Kc = Ks + cur * S::K_HALFS;
         const T* Vc = Vt + cur * S::V_HALFS;
-        if (kt + 1 < n_tiles) stage.load(Kh, Vh, HD, (kt + 1) * kTile, Tk, d);  // in flight during this tile's work
+        if (kt + 1 < n_tiles) stage.load(Kh, Vh, (int64_t)(kt + 1) * kTile * HD, Tk - (kt + 1) * kTile);  // in flight during this tile's work
 
         // ---- Sᵀ = K·Qᵀ: every K fragment read once, used for all RB row blocks -----------------
         f32x4 s[RB][kNKF];
@@ -180,7 +235,10 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restr
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) o[rb][df] = Mma<T>::k32(vf, pf[rb][kk], o[rb][df]);
             }
-        if (kt + 1 < n_tiles) stage.store(Ks + (cur ^ 1) * S::K_HALFS, Vt + (cur ^ 1) * S::V_HALFS);
+        if (kt + 1 < n_tiles) {
+            stage.store_a_rows(Ks + (cur ^ 1) * S::K_HALFS);
+            stage.store_b_transposed(Vt + (cur ^ 1) * S::V_HALFS);
+        }
         __syncthreads();
     };
     const int n_full = Tk / kTile;
@@ -238,39 +296,6 @@ __global__ __launch_bounds__(256) void attn_flash_delta_kernel(const T* __restri
     }
 }
 
-// K and V tile for the dQ kernel: K row-major + K transposed (permuted keys), V row-major
-template <typename T, int KS, int DF> struct TileRegsDq {
-    using S = FlashShape<KS, DF>;
-    Chunk<T> k[S::IT], v[S::IT];
-    __device__ __forceinline__ void load(const T* Kh, const T* Vh, int64_t HD, int key0, int Tk, int d) {
-#pragma unroll
-        for (int i = 0; i < S::IT; ++i) {
-            const int idx = threadIdx.x + i * 256;
-            const int key = idx / S::CPR, c = (idx - key * S::CPR) * 8;
-            const bool ok = idx < S::N && key0 + key < Tk && c < d;
-            const int64_t off = ok ? (int64_t)(key0 + key) * HD + c : 0;
-            k[i] = load_or_zero<T>(Kh + off, ok);
-            v[i] = load_or_zero<T>(Vh + off, ok);
-        }
-    }
-    __device__ __forceinline__ void store(T* Ks, T* Vs, T* Kt) const {
-#pragma unroll
-        for (int i = 0; i < S::IT; ++i) {
-            const int idx = threadIdx.x + i * 256;
-            const int key = idx / S::CPR, c = (idx - key * S::CPR) * 8;
-            if (idx < S::N) {
-                *reinterpret_cast<Chunk<T>*>(Ks + key * S::KROW + c) = k[i];
-                *reinterpret_cast<Chunk<T>*>(Vs + key * S::KROW + c) = v[i];
-                if (c < S::DV) {
-                    const int pos = key_pos(key);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) Kt[(c + e) * S::TROW + pos] = k[i].v[e];
-                }
-            }
-        }
-    }
-};
-
 template <typename T, int KS, int DF, int RB>
 __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const T* __restrict__ Q, const T* __restrict__ K,
                                                              const T* __restrict__ V, const T* __restrict__ dO,
@@ -309,9 +334,14 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const T* __restri
         for (int df = 0; df < DF; ++df) acc[rb][df] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    TileRegsDq<T, KS, DF> stage;
-    stage.load(Kh, Vh, HD, 0, Tk, d);
-    stage.store(Ks, Vs, Kt);
+    lds_zero(smem, flash_dq_lds_bytes<KS, DF>());
+    __syncthreads();
+    TileStage<T, KS, DF> stage;
+    stage.init(d, HD);
+    stage.load(Kh, Vh, 0, Tk);
+    stage.store_a_rows(Ks);
+    stage.store_b_rows(Vs);
+    stage.store_a_transposed(Kt);
     __syncthreads();
     const int n_tiles = (Tk + kTile - 1) / kTile;
     auto tile = [&](int kt, auto ragged_tag) {
@@ -320,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const T* __restri
         const T* Kc = Ks + cur * S::K_HALFS;
         const T* Vc = Vs + cur * S::K_HALFS;
         const T* Ktc = Kt + cur * S::V_HALFS;
-        if (kt + 1 < n_tiles) stage.load(Kh, Vh, HD, (kt + 1) * kTile, Tk, d);
+        if (kt + 1 < n_tiles) stage.load(Kh, Vh, (int64_t)(kt + 1) * kTile * HD, Tk - (kt + 1) * kTile);
 
         f32x4 s[RB][kNKF], dp[RB][kNKF];
 #pragma unroll
@@ -365,8 +395,11 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const T* __restri
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) acc[rb][df] = Mma<T>::k32(ktf, dsf[rb][kk], acc[rb][df]);
             }
-        if (kt + 1 < n_tiles)
-            stage.store(Ks + (cur ^ 1) * S::K_HALFS, Vs + (cur ^ 1) * S::K_HALFS, Kt + (cur ^ 1) * S::V_HALFS);
+        if (kt + 1 < n_tiles) {
+            stage.store_a_rows(Ks + (cur ^ 1) * S::K_HALFS);
+            stage.store_b_rows(Vs + (cur ^ 1) * S::K_HALFS);
+            stage.store_a_transposed(Kt + (cur ^ 1) * S::V_HALFS);
+        }
         __syncthreads();
     };
     const int n_full = Tk / kTile;
@@ -390,37 +423,16 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const T* __restri
     }
 }
 
-// one 64-row tile of Q and dO (row-major) plus LSE and Δ of those rows, global → registers → LDS
-template <typename T, int KS, int DF> struct QTileRegs {
-    using S = FlashShape<KS, DF>;
-    Chunk<T> q[S::IT], g[S::IT];
-    float lse, delta;  // threads 0..63 carry one row's statistics
-    __device__ __forceinline__ void load(const T* Qh, const T* Gh, const float* lse_h, const float* delta_h, int64_t HD,
-                                         int row0, int Tq, int d) {
-#pragma unroll
-        for (int i = 0; i < S::IT; ++i) {
-            const int idx = threadIdx.x + i * 256;
-            const int row = idx / S::CPR, c = (idx - row * S::CPR) * 8;
-            const bool ok = idx < S::N && row0 + row < Tq && c < d;
-            const int64_t off = ok ? (int64_t)(row0 + row) * HD + c : 0;
-            q[i] = load_or_zero<T>(Qh + off, ok);
-            g[i] = load_or_zero<T>(Gh + off, ok);
-        }
+// LSE and Δ of one 64-row query tile: threads 0..63 carry one row each (+inf / 0 past the end: probability 0)
+struct RowStats {
+    float lse, delta;
+    __device__ __forceinline__ void load(const float* lse_h, const float* delta_h, int row0, int Tq) {
         const int r = row0 + (int)(threadIdx.x & 63);
         const bool ok = r < Tq;
         lse = ok ? lse_h[ok ? r : 0] : INFINITY;
         delta = ok ? delta_h[ok ? r : 0] : 0.f;
     }
-    __device__ __forceinline__ void store(T* Qs, T* Gs, float* lse_s, float* delta_s) const {
-#pragma unroll
-        for (int i = 0; i < S::IT; ++i) {
-            const int idx = threadIdx.x + i * 256;
-            const int row = idx / S::CPR, c = (idx - row * S::CPR) * 8;
-            if (idx < S::N) {
-                *reinterpret_cast<Chunk<T>*>(Qs + row * S::KROW + c) = q[i];
-                *reinterpret_cast<Chunk<T>*>(Gs + row * S::KROW + c) = g[i];
-            }
-        }
+    __device__ __forceinline__ void store(float* lse_s, float* delta_s) const {
         if (threadIdx.x < 64) {
             lse_s[threadIdx.x] = lse;
             delta_s[threadIdx.x] = delta;
@@ -473,9 +485,16 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
 #pragma unroll
         for (int df = 0; df < DF; ++df) dk[nf][df] = dv[nf][df] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    QTileRegs<T, KS, DF> stage;
-    stage.load(Qh, Gh, lse_h, delta_h, HD, 0, Tq, d);
-    stage.store(Qs, Gs, lse_s, delta_s);
+    lds_zero(smem, flash_dkdv_lds_bytes<KS, DF>());
+    __syncthreads();
+    TileStage<T, KS, DF> stage;
+    RowStats stats;
+    stage.init(d, HD);
+    stage.load(Qh, Gh, 0, Tq);
+    stats.load(lse_h, delta_h, 0, Tq);
+    stage.store_a_rows(Qs);
+    stage.store_b_rows(Gs);
+    stats.store(lse_s, delta_s);
     __syncthreads();
     const int n_tiles = (Tq + 63) / 64;
     for (int qt = 0; qt < n_tiles; ++qt) {
@@ -484,7 +503,10 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
         const T* Gc = Gs + cur * S::K_HALFS;
         const float* lc = lse_s + cur * 64;
         const float* dc = delta_s + cur * 64;
-        if (qt + 1 < n_tiles) stage.load(Qh, Gh, lse_h, delta_h, HD, (qt + 1) * 64, Tq, d);
+        if (qt + 1 < n_tiles) {
+            stage.load(Qh, Gh, (int64_t)(qt + 1) * 64 * HD, Tq - (qt + 1) * 64);
+            stats.load(lse_h, delta_h, (qt + 1) * 64, Tq);
+        }
         const bool keys_ragged = key0 + 16 * NKW > Tk;  // wave-uniform: only the last wave of the last workgroup
         if constexpr (PAIR) {
 #pragma unroll 1
@@ -580,9 +602,11 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
                 }
             }
         }
-        if (qt + 1 < n_tiles)
-            stage.store(Qs + (cur ^ 1) * S::K_HALFS, Gs + (cur ^ 1) * S::K_HALFS, lse_s + (cur ^ 1) * 64,
-                        delta_s + (cur ^ 1) * 64);
+        if (qt + 1 < n_tiles) {
+            stage.store_a_rows(Qs + (cur ^ 1) * S::K_HALFS);
+            stage.store_b_rows(Gs + (cur ^ 1) * S::K_HALFS);
+            stats.store(lse_s + (cur ^ 1) * 64, delta_s + (cur ^ 1) * 64);
+        }
         __syncthreads();
     }
 #pragma unroll
@@ -622,10 +646,7 @@ bool plan_flash(int B, int Tq, int Tk, int H, int d, FlashPlan* pl) {
     return true;
 }
 
-template <int KS, int DF> constexpr int flash_fwd_lds() {
-    using S = FlashShape<KS, DF>;
-    return 2 * (S::K_HALFS + S::V_HALFS) * 2;
-}
+template <int KS, int DF> constexpr int flash_fwd_lds() { return flash_fwd_lds_bytes<KS, DF>(); }
 
 struct FlashArgs {
     const void *Q, *K, *V;
@@ -661,14 +682,8 @@ int dispatch_flash_fwd(const FlashArgs& a, const FlashPlan& pl, hipStream_t stre
     return LORA_E_BADARG;
 }
 
-template <int KS, int DF> constexpr int flash_dq_lds() {
-    using S = FlashShape<KS, DF>;
-    return (4 * S::K_HALFS + 2 * S::V_HALFS) * 2;
-}
-template <int KS, int DF> constexpr int flash_dkdv_lds() {
-    using S = FlashShape<KS, DF>;
-    return 4 * S::K_HALFS * 2 + 4 * 64 * 4;
-}
+template <int KS, int DF> constexpr int flash_dq_lds() { return flash_dq_lds_bytes<KS, DF>(); }
+template <int KS, int DF> constexpr int flash_dkdv_lds() { return flash_dkdv_lds_bytes<KS, DF>(); }
 
 struct FlashBwdArgs {
     const void *Q, *K, *V, *O, *dO;
