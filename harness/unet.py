@@ -97,7 +97,8 @@ class ResnetBlock2D(nn.Module):
 
 
 class CrossAttention(nn.Module):
-    """q/k/v/out projections are the LoRA targets; the attention core is stock SDPA."""
+    """q/k/v/out projections are the LoRA targets; the attention core is stock SDPA until the caller switches the HIP
+    cores on with the reference's hook (`set_use_memory_efficient_attention_xformers(unet, True)`)."""
 
     def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64):
         super().__init__()
