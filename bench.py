@@ -41,7 +41,64 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --shared-gpu rehearses N ranks on one GPU")
     ap.add_argument("--shared-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--stub-body", default=None, choices=["ok", "fail"],
+                    help="test hook: ranks only rendezvous over gloo on the CPU and rank 0 prints a stub JSON line "
+                         "('fail': rank 1 exits non-zero) — exercises the launcher without a GPU")
     return ap.parse_args()
+
+
+def _free_port() -> int:
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` called directly (no WORLD_SIZE in the environment): start N fresh rank processes, one
+    per GPU, the way the reference starts its trainer (`accelerate launch`, training_scripts/run_lora_db_unet_only.sh:6 —
+    here `python -m torch.distributed.run`), relay rank 0's JSON line and propagate a non-zero exit code.  The parent
+    never touches the GPU and never replaces itself: the ranks are children."""
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cpus() // n)))
+    log(f"launcher: starting {n} ranks: {' '.join(cmd[1:])}")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in proc.stdout:  # rank 0's result line (and anything else the ranks print) goes to our stdout as it comes
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    rc = proc.wait()
+    if rc != 0:
+        log(f"launcher: ranks exited with code {rc}")
+    return rc
+
+
+def stub_body(args, rank, world):
+    """Launcher test body (CPU only): every rank joins a gloo group and contributes to one all-reduce; rank 0 prints a
+    line with the contract's keys.  'fail' makes rank 1 exit non-zero so the launcher's error propagation is visible."""
+    import torch.distributed as dist
+
+    if args.stub_body == "fail" and rank == 1:
+        sys.exit(3)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)])
+    if world > 1:
+        dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": float(t.item()), "unit": "ranksum", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "stub": True}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def build_model(device, dtype, rank_r):
@@ -143,13 +200,15 @@ def cpu_baseline(latent, rank_r, steps):
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under a launcher: become one (before anything in this process has touched the GPU)
+        raise SystemExit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-        args.gpus = world
+    args.gpus = world
+    if args.stub_body:
+        return stub_body(args, rank, world)
     import torch.distributed as dist
 
     torch.set_num_threads(max(1, usable_cpus() // max(1, world if world <= 8 else 8)))
@@ -205,7 +264,13 @@ def main():
 
         t_host = trial()
         trainer.capture_graph = True
-        trainer.step(*data[0])  # records (falls back to host launches by itself if the recording fails)
+        # records; a rank whose recording fails finishes this step host-launched with the SAME single whole-slab
+        # all-reduce a replay issues (LoraTrainer._step_graph), so the collectives stay matched whatever happens
+        trainer.step(*data[0])
+        ok = torch.tensor([1.0 if trainer.capture_graph else 0.0], device=device)
+        if world > 1:  # agree on the launch mode BEFORE any further step: the two modes bucket the exchange differently
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        trainer.capture_graph = bool(ok.item() > 0)
         t_graph = trial() if trainer.capture_graph else float("inf")
         keep = torch.tensor([1.0 if t_graph <= 1.05 * t_host else 0.0], device=device)
         if world > 1:

@@ -343,6 +343,13 @@ class LoraTrainer:
         if self.capture_graph and mask is None and self.text_encoder is None:
             return self._step_graph(latents, noise, timesteps, encoder_hidden_states, with_prior_preservation,
                                     prior_loss_weight, seed)
+        return self._step_eager(latents, noise, timesteps, encoder_hidden_states, with_prior_preservation,
+                                prior_loss_weight, mask, seed, early_bucket=True)
+
+    def _step_eager(self, latents, noise, timesteps, encoder_hidden_states, with_prior_preservation, prior_loss_weight,
+                    mask, seed, early_bucket):
+        """Host-launched step.  early_bucket=False sends the slab in ONE all-reduce after backward — the collective
+        sequence of a hipGraph step — so a rank whose graph recording failed stays matched with ranks that replay."""
         self.slab.zero_grad()
         self.slab.repack()  # packed compute-dtype factors follow the fp32 masters (also after external edits)
         if noise is None:
@@ -353,7 +360,8 @@ class LoraTrainer:
         else:
             noisy, target = nat.ddpm_add_noise(latents, noise, timesteps, self.sqrt_acp, self.sqrt_1macp, self.dtype,
                                                self.v_prediction)
-        self.exchange.arm()
+        if early_bucket:
+            self.exchange.arm()
         pred = self.unet(noisy, timesteps, encoder_hidden_states.to(self.dtype)).sample
         rows = pred.shape[0]
         n_inst, n_prior = (rows // 2, rows // 2) if with_prior_preservation else (rows, 0)
@@ -432,8 +440,9 @@ class LoraTrainer:
 
                 warnings.warn(f"LoraTrainer: hipGraph capture failed ({exc!r}); continuing with eager steps")
                 self.capture_graph, self._graph = False, None
-                return self.step(latents, noise, timesteps, ehs, with_prior_preservation=prior,
-                                 prior_loss_weight=prior_weight, seed=seed)
+                # THIS step still exchanges like a graph step (one all-reduce): peers may have recorded fine
+                return self._step_eager(latents, noise, timesteps, ehs, prior, prior_weight, None, seed,
+                                        early_bucket=False)
             self._graph = st
             # the warm-up passes left valid partial sums of THIS step's inputs, but replay once so that every step
             # (including the first) is produced by the same recorded kernels
