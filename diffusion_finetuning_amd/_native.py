@@ -44,6 +44,8 @@ SIGNATURES = {
     "lora_mse_workspace_bytes": (_i64, []),
     "lora_mask_prepare": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "lora_merge_weight": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
+    "lora_merge_weight_batched": (_i32, [_vp, _i32, _i64, _f32, _vp]),
+    "lora_lerp": (_i32, [_vp, _vp, _i64, _f32, _f32, _i32, _vp]),
     "lora_cast_matrix": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
     "lora_grad_sqnorm": (_i32, [_vp, _i64, _f32, _vp, _vp, _vp]),
     "lora_sqnorm_workspace_bytes": (_i64, []),
@@ -138,6 +140,20 @@ def _require_device(*tensors) -> None:
                 "diffusion_finetuning_amd: the LoRA hot path runs only on a HIP device (MI355X); got a "
                 f"{t.device} tensor. Move the model and inputs to 'cuda'. There is no CPU fallback."
             )
+
+
+def staging_device(*tensors) -> torch.device:
+    """The HIP device host-resident operands are staged through: the device of the first device tensor given, else the
+    current HIP device.  Raises (never computes on the CPU) when there is none."""
+    for t in tensors:
+        if t is not None and t.is_cuda:
+            return t.device
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "diffusion_finetuning_amd: this operation runs as a HIP kernel and no HIP device (MI355X) is visible; "
+            "host tensors are staged through the device, there is no CPU implementation."
+        )
+    return torch.device("cuda", torch.cuda.current_device())
 
 
 def lora_pack_factors(a, b, dtype: torch.dtype):
@@ -290,6 +306,30 @@ def lora_merge_weight(w, a, b, alpha: float, factor_dtype: torch.dtype = torch.f
     _check(lib().lora_merge_weight(_ptr(w), _ptr(a), _ptr(b), K, N, r, float(alpha), dtype_code(w.dtype),
                                    dtype_code(factor_dtype), _stream(w)),
            "lora_merge_weight")
+
+
+def lora_merge_weight_batched(entries, alpha: float) -> None:
+    """entries: [(W [N,K] device tensor (merged in place), a [r,K] fp32, b [N,r] fp32, factor_dtype), ...] — one launch."""
+    if not entries:
+        return
+    rows, max_elems = [], 1
+    for w, a, b, fdt in entries:
+        _require_device(w, a, b)
+        N, K = w.shape
+        rows.append([w.data_ptr(), a.data_ptr(), b.data_ptr(), K, N, a.shape[0], dtype_code(w.dtype), dtype_code(fdt)])
+        max_elems = max(max_elems, N * K)
+    dev = entries[0][0].device
+    table = torch.tensor(rows, dtype=torch.int64).to(dev)
+    _check(lib().lora_merge_weight_batched(_ptr(table), len(rows), max_elems, float(alpha), _stream(entries[0][0])),
+           "lora_merge_weight_batched")
+
+
+def lora_lerp_(x1, x2, alpha: float) -> None:
+    """In place x1 ← T(T(alpha·x1) + T((1-alpha)·x2)) on flat device tensors of one dtype (cli_lora_add.py:52-55)."""
+    _require_device(x1, x2)
+    assert x1.dtype == x2.dtype and x1.numel() == x2.numel() and x1.is_contiguous() and x2.is_contiguous()
+    _check(lib().lora_lerp(_ptr(x1), _ptr(x2), x1.numel(), float(alpha), float(1 - alpha), dtype_code(x1.dtype),
+                           _stream(x1)), "lora_lerp")
 
 
 def lora_cast_matrix(src, dst_dtype: torch.dtype, transpose: bool):

@@ -163,21 +163,25 @@ def extract_lora_ups_down(model, target_replace_module=DEFAULT_TARGET_REPLACE):
 
 
 def weight_apply_lora(model, loras, target_replace_module=DEFAULT_TARGET_REPLACE, alpha=1.0):
-    """W ← W + α·(up @ down).type(W.dtype) for every target nn.Linear, as a NEW Parameter (lora.py:410-424).
-    Runs as one HIP kernel per layer (csrc/optim.hip: merge_kernel); the weights must live on the device."""
-    for _, _, child in _find_modules(model, target_replace_module, search_class=[nn.Linear]):
+    """W ← W + α·(up @ down).type(W.dtype) for every target nn.Linear, as a NEW Parameter on the weight's own device
+    (lora.py:410-424).  All layers are merged by ONE HIP launch (csrc/optim.hip: merge_batched_kernel).  Weights that
+    live on the host — the reference's `lora_add` moves the pipeline to the CPU first, cli_lora_add.py:74-78 — are
+    staged through the HIP device and handed back; nothing is computed on the CPU."""
+    targets = [child for _, _, child in _find_modules(model, target_replace_module, search_class=[nn.Linear])]
+    if not targets:
+        return
+    device = nat.staging_device(*(c.weight for c in targets))  # raises before `loras` is touched
+    entries = []
+    for child in targets:
         weight = child.weight
-        up = loras.pop(0).detach().to(weight.device)
-        down = loras.pop(0).detach().to(weight.device)
-        if not weight.is_cuda:
-            raise RuntimeError(
-                "weight_apply_lora: the merge runs as a HIP kernel; move the model to 'cuda' first "
-                "(there is no CPU fallback)."
-            )
-        merged = weight.detach().clone().contiguous()
+        up, down = loras.pop(0), loras.pop(0)
+        merged = weight.detach().to(device, copy=True).contiguous()
         held = up.dtype if up.dtype in (torch.float16, torch.bfloat16) else torch.float32
-        nat.lora_merge_weight(merged, down.float().contiguous(), up.float().contiguous(), alpha, held)
-        child.weight = nn.Parameter(merged)
+        entries.append((merged, down.detach().to(device).float().contiguous(),
+                        up.detach().to(device).float().contiguous(), held))
+    nat.lora_merge_weight_batched(entries, alpha)
+    for child, entry in zip(targets, entries):
+        child.weight = nn.Parameter(entry[0].to(child.weight.device))
 
 
 def monkeypatch_lora(model, loras, target_replace_module=DEFAULT_TARGET_REPLACE, r: int = 4):

@@ -132,6 +132,48 @@ __global__ __launch_bounds__(256) void merge_kernel(T* W, const float* A, const 
     }
 }
 
+// Every layer of a model in ONE launch: blockIdx.y = layer, table[l] = {W, A, B, K, N, r, dtype, factor_dtype}
+// (device pointers as int64).  Same arithmetic as merge_kernel.
+template <typename T>
+__device__ __forceinline__ void merge_rows(T* W, const float* A, const float* B, int K, int N, int r, float alpha,
+                                           int factor_dtype) {
+    const int64_t total = (int64_t)N * K;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int n = (int)(i / K), k = (int)(i - (int64_t)n * K);
+        float d = 0.f;
+        for (int j = 0; j < r; ++j) d = fmaf(B[(int64_t)n * r + j], A[(int64_t)j * K + k], d);
+        if (factor_dtype == LORA_F16) d = to_f32<half_t>(from_f32<half_t>(d));
+        if (factor_dtype == LORA_BF16) d = to_f32<bf16_t>(from_f32<bf16_t>(d));
+        const T dt = from_f32<T>(d);
+        const T upd = from_f32<T>(alpha * to_f32<T>(dt));
+        W[i] = from_f32<T>(to_f32<T>(W[i]) + to_f32<T>(upd));
+    }
+}
+__global__ __launch_bounds__(256) void merge_batched_kernel(const int64_t* table, float alpha) {
+    const int64_t* e = table + (int64_t)blockIdx.y * 8;
+    void* W = reinterpret_cast<void*>(e[0]);
+    const float* A = reinterpret_cast<const float*>(e[1]);
+    const float* B = reinterpret_cast<const float*>(e[2]);
+    const int K = (int)e[3], N = (int)e[4], r = (int)e[5], fd = (int)e[7];
+    switch ((int)e[6]) {
+        case LORA_F32: merge_rows<float>(static_cast<float*>(W), A, B, K, N, r, alpha, fd); break;
+        case LORA_F16: merge_rows<half_t>(static_cast<half_t*>(W), A, B, K, N, r, alpha, fd); break;
+        case LORA_BF16: merge_rows<bf16_t>(static_cast<bf16_t*>(W), A, B, K, N, r, alpha, fd); break;
+        default: break;
+    }
+}
+
+// LoRA (+) LoRA interpolation of lora_diffusion/cli_lora_add.py:52-55, op by op in the tensors' own dtype:
+//   x1 = T( T(a·x1) + T(b·x2) )      a = alpha, b = 1 - alpha
+template <typename T>
+__global__ __launch_bounds__(256) void lerp_kernel(T* x1, const T* x2, int64_t n, float a, float b) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const T p = from_f32<T>(a * to_f32<T>(x1[i]));
+        const T q = from_f32<T>(b * to_f32<T>(x2[i]));
+        x1[i] = from_f32<T>(to_f32<T>(p) + to_f32<T>(q));
+    }
+}
+
 template <typename S, typename D>
 __global__ __launch_bounds__(256) void cast_matrix_kernel(const S* src, D* dst, int64_t rows, int64_t cols,
                                                           int transpose) {
@@ -240,6 +282,41 @@ extern "C" int lora_merge_weight(void* W, const float* A, const float* B, int K,
         case LORA_BF16:
             hipLaunchKernelGGL(merge_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<bf16_t*>(W),
                                A, B, K, N, r, alpha, factor_dtype);
+            break;
+        default: return LORA_E_BADARG;
+    }
+    LORA_LAUNCH_CHECK();
+    return LORA_OK;
+}
+
+extern "C" int lora_merge_weight_batched(const int64_t* table, int n_layers, int64_t max_elems, float alpha,
+                                         void* stream) {
+    if (!table || n_layers < 1 || max_elems < 1) return LORA_E_BADARG;
+    int64_t blocks = (max_elems + 1023) / 1024;  // ~4 elements per thread on the largest layer
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(merge_batched_kernel, dim3((unsigned)blocks, (unsigned)n_layers), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), table, alpha);
+    LORA_LAUNCH_CHECK();
+    return LORA_OK;
+}
+
+extern "C" int lora_lerp(void* x1, const void* x2, int64_t n, float a, float b, int dtype, void* stream) {
+    if (!x1 || !x2 || n < 1) return LORA_E_BADARG;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case LORA_F32:
+            hipLaunchKernelGGL(lerp_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<float*>(x1),
+                               static_cast<const float*>(x2), n, a, b);
+            break;
+        case LORA_F16:
+            hipLaunchKernelGGL(lerp_kernel<half_t>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<half_t*>(x1),
+                               static_cast<const half_t*>(x2), n, a, b);
+            break;
+        case LORA_BF16:
+            hipLaunchKernelGGL(lerp_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<bf16_t*>(x1),
+                               static_cast<const bf16_t*>(x2), n, a, b);
             break;
         default: return LORA_E_BADARG;
     }

@@ -143,6 +143,34 @@ def load_safeloras_both(path, device="cpu"):
     return parse_safeloras(handle), parse_safeloras_embeds(handle)
 
 
+def lerp_lora_lists(l1: List[torch.Tensor], l2: List[torch.Tensor], alpha: float = 0.5) -> List[torch.Tensor]:
+    """LoRA ⊕ LoRA of `lora_add --mode lpl` (lora_diffusion/cli_lora_add.py:44-60) on two positional
+    `[up0, down0, up1, ...]` lists: every tensor of `l1` becomes alpha·l1 + (1-alpha)·l2 IN PLACE (`.data` is
+    replaced, dtype and device kept, op-by-op rounding as the reference) and the list of merged tensors is returned,
+    ready for `torch.save`.  One HIP launch per dtype over the concatenated lists (host tensors are staged through
+    the device).  A trailing unpaired tensor is dropped, like the reference's pair zip."""
+    from . import _native as nat
+
+    n = 2 * min(len(l1) // 2, len(l2) // 2)
+    if n == 0:
+        return []
+    for x1, x2 in zip(l1[:n], l2[:n]):
+        if x1.shape != x2.shape:
+            raise RuntimeError(f"lerp_lora_lists: LoRA tensors differ in shape: {tuple(x1.shape)} vs {tuple(x2.shape)}")
+    device = nat.staging_device(*l1[:n])
+    for dtype in {t.dtype for t in l1[:n]}:
+        idx = [i for i in range(n) if l1[i].dtype == dtype]
+        a = torch.cat([l1[i].detach().to(device).reshape(-1) for i in idx])
+        b = torch.cat([l2[i].detach().to(device, dtype).reshape(-1) for i in idx])
+        nat.lora_lerp_(a, b, alpha)
+        off = 0
+        for i in idx:
+            k = l1[i].numel()
+            l1[i].data = a[off:off + k].view(l1[i].shape).to(l1[i].device, copy=True)
+            off += k
+    return list(l1[:n])
+
+
 def _derived_path(path: str, tag: str) -> str:
     assert path.endswith(".pt"), "Only .pt files are supported"
     return ".".join(path.split(".")[:-1] + [tag, "pt"])

@@ -31,6 +31,31 @@ def monkeypatch_or_replace_safeloras(models, safeloras):
         monkeypatch_or_replace_lora(model, lora, target, ranks)
 
 
+def _token_list(learned_embeds, token) -> List[str]:
+    """Which names the learned vectors are registered under: the file's own keys, one override, or a list of them."""
+    if token is None:
+        return list(learned_embeds.keys())
+    if isinstance(token, str):
+        return [token]
+    assert len(learned_embeds.keys()) == len(token), "The number of tokens and the number of embeds should be the same"
+    return list(token)
+
+
+def _register_token(tokenizer, token: str, idempotent: bool) -> str:
+    """Adds `token` to the tokenizer.  If it exists already: keep it (idempotent — its row is overwritten) or find a
+    free variant `<name-1>`, `<name-1-2>`, ... (the reference's renaming rule, lora.py:634-646).  Returns the name used."""
+    if tokenizer.add_tokens(token) or idempotent:
+        return token
+    name, n = token, 1
+    while True:  # "<s>" → "<s-1>" → "<s-1-2>" → ...: each retry extends the previous candidate, like the reference
+        name = f"{name[:-1]}-{n}>"
+        if tokenizer.add_tokens(name):
+            break
+        n += 1
+    print(f"token {token} is taken; registered the embedding as {name}")
+    return name
+
+
 def apply_learned_embed_in_clip(
     learned_embeds,
     text_encoder,
@@ -38,37 +63,18 @@ def apply_learned_embed_in_clip(
     token: Optional[Union[str, List[str]]] = None,
     idempotent=False,
 ):
-    """Adds learned tokens to the tokenizer and writes their rows into the CLIP embedding table
-    (lora.py:613-656)."""
-    if isinstance(token, str):
-        tokens = [token]
-    elif isinstance(token, list):
-        assert len(learned_embeds.keys()) == len(
-            token
-        ), "The number of tokens and the number of embeds should be the same"
-        tokens = token
-    else:
-        tokens = list(learned_embeds.keys())
-
-    for token in tokens:
-        print(token)
-        vector = learned_embeds[token]
-        added = tokenizer.add_tokens(token)
-        if not idempotent:
-            suffix = 1
-            while added == 0:
-                print(f"The tokenizer already contains the token {token}.")
-                token = f"{token[:-1]}-{suffix}>"
-                print(f"Attempting to add the token {token}.")
-                added = tokenizer.add_tokens(token)
-                suffix += 1
-        elif added == 0:
-            print(f"The tokenizer already contains the token {token}.")
-            print(f"Replacing {token} embedding.")
+    """Registers learned textual-inversion vectors: each name goes into the tokenizer and its vector into the matching
+    row of the CLIP input-embedding table (reference behaviour: lora.py:613-656).  Vectors are looked up under the
+    REQUESTED name (so an override must be a key of `learned_embeds`, as in the reference); returns the last name
+    actually registered."""
+    used = None
+    for name in _token_list(learned_embeds, token):
+        vector = learned_embeds[name]
+        used = _register_token(tokenizer, name, idempotent)
         text_encoder.resize_token_embeddings(len(tokenizer))
-        row = tokenizer.convert_tokens_to_ids(token)
-        text_encoder.get_input_embeddings().weight.data[row] = vector
-    return token
+        table = text_encoder.get_input_embeddings().weight
+        table.data[tokenizer.convert_tokens_to_ids(used)] = vector
+    return used
 
 
 def load_learned_embed_in_clip(
@@ -80,6 +86,18 @@ def load_learned_embed_in_clip(
 ):
     learned = torch.load(learned_embeds_path, map_location="cpu", weights_only=True)
     apply_learned_embed_in_clip(learned, text_encoder, tokenizer, token, idempotent)
+
+
+def _unet_pt_path(path: str) -> str:
+    """`x.ti.pt` / `x.text_encoder.pt` / `x.pt` all name the same triple; its UNet member is `x.pt`."""
+    for suffix in (".ti.pt", ".text_encoder.pt"):
+        if path.endswith(suffix):
+            return path[: -len(suffix)] + ".pt"
+    return path  # (the reference leaves the plain `x.pt` case undefined: NameError)
+
+
+def _load_list(path):
+    return torch.load(path, map_location="cpu", weights_only=True)
 
 
 def patch_pipe(
@@ -94,42 +112,31 @@ def patch_pipe(
     unet_target_replace_module=DEFAULT_TARGET_REPLACE,
     text_target_replace_module=TEXT_ENCODER_DEFAULT_TARGET_REPLACE,
 ):
-    """Loads a `.pt` triple or one `.safetensors` into a diffusers pipeline (lora.py:672-732)."""
-    if maybe_unet_path.endswith(".pt"):
-        if maybe_unet_path.endswith(".ti.pt"):
-            unet_path = maybe_unet_path[:-6] + ".pt"
-        elif maybe_unet_path.endswith(".text_encoder.pt"):
-            unet_path = maybe_unet_path[:-16] + ".pt"
-        else:
-            unet_path = maybe_unet_path  # the reference leaves this case undefined (NameError)
-
-        if patch_unet:
-            print("LoRA : Patching Unet")
-            monkeypatch_or_replace_lora(
-                pipe.unet,
-                torch.load(unet_path, map_location="cpu", weights_only=True),
-                r=r,
-                target_replace_module=unet_target_replace_module,
-            )
-        if patch_text:
-            print("LoRA : Patching text encoder")
-            monkeypatch_or_replace_lora(
-                pipe.text_encoder,
-                torch.load(_text_lora_path(unet_path), map_location="cpu", weights_only=True),
-                target_replace_module=text_target_replace_module,
-                r=r,
-            )
-        if patch_ti:
-            print("LoRA : Patching token input")
-            token = load_learned_embed_in_clip(
-                _ti_lora_path(unet_path), pipe.text_encoder, pipe.tokenizer, token=token, idempotent=idempotent_token
-            )
-    elif maybe_unet_path.endswith(".safetensors"):
+    """Installs LoRA factors (and learned tokens) from files into a diffusers-style pipeline object with `.unet`,
+    `.text_encoder`, `.tokenizer` (reference: lora.py:672-732).  A `.safetensors` file carries everything and is
+    applied whole; a `.pt` path names a triple (`x.pt`, `x.text_encoder.pt`, `x.ti.pt`) of which the `patch_*` flags
+    pick the members.  Other suffixes are ignored, as in the reference."""
+    if maybe_unet_path.endswith(".safetensors"):
         handle = safe_open(maybe_unet_path, framework="pt", device="cpu")
         monkeypatch_or_replace_safeloras(pipe, handle)
-        apply_learned_embed_in_clip(
-            parse_safeloras_embeds(handle), pipe.text_encoder, pipe.tokenizer, token=token, idempotent=idempotent_token
-        )
+        apply_learned_embed_in_clip(parse_safeloras_embeds(handle), pipe.text_encoder, pipe.tokenizer, token=token,
+                                    idempotent=idempotent_token)
+        return
+    if not maybe_unet_path.endswith(".pt"):
+        return
+    unet_path = _unet_pt_path(maybe_unet_path)
+    members = (
+        (patch_unet, "unet", pipe.unet, unet_path, unet_target_replace_module),
+        (patch_text, "text encoder", pipe.text_encoder, _text_lora_path(unet_path), text_target_replace_module),
+    )
+    for wanted, label, model, path, targets in members:
+        if wanted:
+            print(f"LoRA: patching the {label} from {path}")
+            monkeypatch_or_replace_lora(model, _load_list(path), target_replace_module=targets, r=r)
+    if patch_ti:
+        print(f"LoRA: adding learned tokens from {_ti_lora_path(unet_path)}")
+        load_learned_embed_in_clip(_ti_lora_path(unet_path), pipe.text_encoder, pipe.tokenizer, token=token,
+                                   idempotent=idempotent_token)
 
 
 @torch.no_grad()

@@ -143,6 +143,18 @@ int lora_mask_prepare(const float* mask_in, float* mask_out, int B, int Hin, int
 int lora_merge_weight(void* W, const float* A, const float* B, int K, int N, int r, float alpha,
                       int dtype, int factor_dtype, void* stream);
 
+/* The same merge for every layer of a model in ONE launch (cli_lora_add.py:72-88 `upl`: 192.6 M base weights of an
+ * SD1.5 UNet, one HBM pass).  table: device memory, int64 [n_layers][8] =
+ * {W ptr, A ptr (fp32 [r,K]), B ptr (fp32 [N,r]), K, N, r, dtype of W, factor_dtype}; max_elems = max N·K. */
+int lora_merge_weight_batched(const int64_t* table, int n_layers, int64_t max_elems, float alpha, void* stream);
+
+/*
+ * LoRA (+) LoRA interpolation — lora_diffusion/cli_lora_add.py:52-55 (mode `lpl`), op by op in the tensors' dtype:
+ *     x1 ← T( T(a·x1) + T(b·x2) )        with a = alpha, b = 1 − alpha
+ * over n elements (the caller concatenates a whole `[up0, down0, …]` list into one buffer).
+ */
+int lora_lerp(void* x1, const void* x2, int64_t n, float a, float b, int dtype, void* stream);
+
 /* Out-of-place transpose+cast helper used to build the cached operands:
  * dst[cols,rows] (dst_dtype) = src[rows,cols] (src_dtype)ᵀ ; transpose=0 gives a plain cast. */
 int lora_cast_matrix(const void* src, void* dst, int64_t rows, int64_t cols, int src_dtype,
