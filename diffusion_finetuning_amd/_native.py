@@ -21,6 +21,19 @@ _DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 _vp, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
 
 
+class GradProblem(ctypes.Structure):
+    """lora_grad_problem of include/lora_hip.h (host memory, consumed during the call)."""
+    _fields_ = [
+        ("S", _vp), ("P", _vp), ("out", _vp * 4),
+        ("s_stride", _i64), ("p_stride", _i64), ("part_stride", _i64), ("M", _i64),
+        ("C", _i32), ("r", _i32), ("rg", _i32), ("out_kn", _i32), ("n_blocks", _i32),
+        ("scale", _f32),
+    ]
+
+
+GRAD_MAX_BLOCKS = 64
+
+
 class ProfTotals(ctypes.Structure):
     _fields_ = [
         ("launches", _i64 * PROF_KINDS),
@@ -40,6 +53,12 @@ SIGNATURES = {
     "lora_linear_bwd_input": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
     "lora_linear_bwd_params": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
     "lora_reduce_partials": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp]),
+    "lora_grad_row_blocks": (_i32, [_i64]),
+    "lora_grad_batched": (_i32, [ctypes.POINTER(GradProblem), _i32, _i32, _vp]),
+    "lora_fold_partials": (_i32, [_vp, _i32, _i64, _vp, _i64, _vp, _i32, _vp]),
+    "lora_gemm_packed": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _f32,
+                                _i64, _i32, _vp]),
+    "lora_pack_items": (_i32, [_vp, _i32, _i32, _vp, _vp, _i32, _vp]),
     "ddpm_mse_fwd_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i64, _i64, _f32, _f32, _vp, _vp, _vp, _i32, _vp]),
     "lora_mse_workspace_bytes": (_i64, []),
     "lora_mask_prepare": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -61,6 +80,10 @@ SIGNATURES = {
     "attn_ctx_supported": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "attn_ctx_fwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "attn_ctx_bwd_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
+    "attn_ctx_fwd_strided": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "attn_ctx_bwd_strided": (_i32, [_vp] * 8 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "attn_flash_fwd_strided": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "attn_flash_bwd_strided": (_i32, [_vp] * 10 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "attn_ctx_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "attn_flash_supported": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "attn_flash_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
@@ -233,6 +256,65 @@ def lora_linear_bwd_params_partial(dy2, x2, t, u, ga_part, gb_part, part_stride:
                                      dtype_code(dy2.dtype), _stream(dy2)),
         "lora_linear_bwd_params",
     )
+
+
+_row_blocks_cache = {}
+
+
+def grad_row_blocks(M: int) -> int:
+    """Row blocks lora_grad_batched uses for a problem of M rows when n_blocks is left to the library."""
+    nb = _row_blocks_cache.get(M)
+    if nb is None:
+        nb = _row_blocks_cache[M] = int(lib().lora_grad_row_blocks(int(M)))
+    return nb
+
+
+def grad_problem(S, s_ptr_off: int, s_stride: int, C: int, P, p_ptr_off: int, p_stride: int, r: int, outs, rg: int,
+                 out_kn: bool, part_stride: int, M: int, scale: float, n_blocks: int = 0):
+    """One lora_grad_problem: G[c,j] = scale·Σ_m S[m,c]·P[m,j].  S / P are device tensors, *_ptr_off element offsets of
+    the slice's first column; outs = device pointers (ints) of the rank groups' row-block-0 partials."""
+    q = GradProblem()
+    q.S = S.data_ptr() + s_ptr_off * S.element_size()
+    q.P = P.data_ptr() + p_ptr_off * 4
+    for i, o in enumerate(outs):
+        q.out[i] = o
+    q.s_stride, q.p_stride, q.part_stride, q.M = s_stride, p_stride, part_stride, M
+    q.C, q.r, q.rg, q.out_kn, q.n_blocks, q.scale = C, r, rg, int(out_kn), n_blocks, scale
+    return q
+
+
+def lora_grad_batched(problems, dtype: torch.dtype, device) -> None:
+    """Launches every problem of the list (a few launches whatever its length; tables travel as kernel arguments)."""
+    n = len(problems)
+    if n == 0:
+        return
+    arr = (GradProblem * n)(*problems)
+    stream = _raw_stream(device.index) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream
+    _check(lib().lora_grad_batched(arr, n, dtype_code(dtype), stream), "lora_grad_batched")
+
+
+def lora_fold_partials(ranges, n_ranges: int, max_len: int, partials, part_stride: int, grads, accumulate: bool) -> None:
+    """grads[off:off+len] (+)= Σ_{b<blocks} partials[b·part_stride + off : …] for every row {off, len, blocks, 0} of the
+    int64 device table `ranges`."""
+    _require_device(ranges, partials, grads)
+    _check(lib().lora_fold_partials(_ptr(ranges), int(n_ranges), int(max_len), _ptr(partials), int(part_stride),
+                                    _ptr(grads), int(accumulate), _stream(grads)), "lora_fold_partials")
+
+
+def lora_pack_items(table, n_items: int, max_len: int, params, packed) -> None:
+    _require_device(table, params, packed)
+    _check(lib().lora_pack_items(_ptr(table), n_items, max_len, _ptr(params), _ptr(packed), dtype_code(packed.dtype),
+                                 _stream(params)), "lora_pack_items")
+
+
+def lora_gemm_packed(am, lda: int, bm, bias, fp, qp, tile_part, part_table, n_parts: int, c, p_out, M: int, Kc: int,
+                     Nc: int, r: int, scale: float, work_cols: int = 0) -> None:
+    """C = Am·Bmᵀ + bias + s·P·Qᵀ, P = Am·Fᵀ on packed factors (include/lora_hip.h: lora_gemm_packed).  All operands
+    are device tensors (or None); nothing is allocated here."""
+    _require_device(am, bm, bias, fp, qp, tile_part, part_table, c, p_out)
+    _check(lib().lora_gemm_packed(_ptr(am), int(lda), _ptr(bm), _ptr(bias), _ptr(fp), _ptr(qp), _ptr(tile_part),
+                                  _ptr(part_table), int(n_parts), _ptr(c), _ptr(p_out), int(M), int(Kc), int(Nc), int(r),
+                                  float(scale), int(work_cols), dtype_code(am.dtype), _stream(am)), "lora_gemm_packed")
 
 
 def lora_reduce_partials(partials, part_stride: int, n_blocks: int, grads, n: int, accumulate: bool) -> None:
@@ -462,6 +544,71 @@ def attn_ctx_bwd(q, k, v, dout, heads: int, scale: float):
     _check(lib().attn_ctx_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(dout), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(ws), B, Tq, Tk,
                               heads, d, float(scale), dtype_code(q.dtype), _stream(q)), "attn_ctx_bwd")
     return dq, dk, dv
+
+
+def attn_ctx_fwd_kv(q, kv, off_k: int, off_v: int, heads: int, scale: float):
+    """Cross-attention whose K and V are the column slices [off_k, off_k+H·d) / [off_v, …) of `kv` [B·Tk, ld] (the output
+    of a grouped to_k/to_v projection); q [B,Tq,H·d] contiguous → out [B,Tq,H·d]."""
+    _require_device(q, kv)
+    B, Tq, HD = q.shape
+    ld = kv.shape[-1]
+    Tk = kv.shape[0] // B
+    es = kv.element_size()
+    out = torch.empty_like(q)
+    _check(lib().attn_ctx_fwd_strided(_ptr(q), kv.data_ptr() + off_k * es, kv.data_ptr() + off_v * es, _ptr(out), ld, B,
+                                      Tq, Tk, heads, HD // heads, float(scale), dtype_code(q.dtype), _stream(q)),
+           "attn_ctx_fwd_strided")
+    return out
+
+
+def attn_ctx_bwd_kv(q, kv, dkv, off_k: int, off_v: int, dout, heads: int, scale: float):
+    """Backward of attn_ctx_fwd_kv: returns dq; dK / dV are WRITTEN into the same column slices of `dkv` [B·Tk, ld]."""
+    _require_device(q, kv, dkv, dout)
+    B, Tq, HD = q.shape
+    ld = kv.shape[-1]
+    Tk = kv.shape[0] // B
+    d = HD // heads
+    es = kv.element_size()
+    nbytes = lib().attn_ctx_bwd_workspace_bytes(B, Tq, Tk, heads, d)
+    if nbytes < 0:
+        raise RuntimeError("attn_ctx_bwd: unsupported shape")
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=q.device)
+    dq = torch.empty_like(q)
+    _check(lib().attn_ctx_bwd_strided(_ptr(q), kv.data_ptr() + off_k * es, kv.data_ptr() + off_v * es, _ptr(dout),
+                                      _ptr(dq), dkv.data_ptr() + off_k * es, dkv.data_ptr() + off_v * es, _ptr(ws), ld,
+                                      dkv.shape[-1], B, Tq, Tk, heads, d, float(scale), dtype_code(q.dtype), _stream(q)),
+           "attn_ctx_bwd_strided")
+    return dq
+
+
+def attn_flash_fwd_qkv(qkv, heads: int, scale: float, want_lse: bool = True):
+    """Self-attention on a grouped projection's output qkv [B, T, 3·H·d] (q | k | v column slices) → (o [B,T,H·d], lse)."""
+    _require_device(qkv)
+    B, T, W = qkv.shape
+    HD = W // 3
+    es = qkv.element_size()
+    out = torch.empty((B, T, HD), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B, heads, T), dtype=torch.float32, device=qkv.device) if want_lse else None
+    base = qkv.data_ptr()
+    _check(lib().attn_flash_fwd_strided(base, base + HD * es, base + 2 * HD * es, _ptr(out), _ptr(lse), W, B, T, T, heads,
+                                        HD // heads, float(scale), dtype_code(qkv.dtype), _stream(qkv)),
+           "attn_flash_fwd_strided")
+    return out, lse
+
+
+def attn_flash_bwd_qkv(qkv, out, dout, lse, heads: int, scale: float):
+    """→ dqkv [B, T, 3·H·d] (dq | dk | dv written as column slices of one buffer: the dY of the grouped projection)."""
+    _require_device(qkv, out, dout, lse)
+    B, T, W = qkv.shape
+    HD = W // 3
+    es = qkv.element_size()
+    ws = torch.empty(lib().attn_flash_bwd_workspace_bytes(B, T, heads) // 4, dtype=torch.float32, device=qkv.device)
+    dqkv = torch.empty_like(qkv)
+    base, dbase = qkv.data_ptr(), dqkv.data_ptr()
+    _check(lib().attn_flash_bwd_strided(base, base + HD * es, base + 2 * HD * es, _ptr(out), _ptr(dout), _ptr(lse), dbase,
+                                        dbase + HD * es, dbase + 2 * HD * es, _ptr(ws), W, W, B, T, T, heads, HD // heads,
+                                        float(scale), dtype_code(qkv.dtype), _stream(qkv)), "attn_flash_bwd_strided")
+    return dqkv
 
 
 def attn_flash_supported(B: int, Tq: int, Tk: int, H: int, d: int, dtype) -> bool:

@@ -57,24 +57,41 @@ def _hip_forward(self, hidden_states, *args, **kwargs):
     mask = kwargs.get("attention_mask", kwargs.get("mask", args[1] if len(args) > 1 else None))
     unknown = len(args) > 2 or any(k not in ("encoder_hidden_states", "context", "attention_mask", "mask") for k in kwargs)
     heads = int(self.heads)
-    if ctx is None:
-        ctx = hidden_states  # self-attention
+    self_attention = ctx is None
+    if self_attention:
+        ctx = hidden_states
     core = None
+    cdtype = _compute_dtype(hidden_states)
     if (not unknown and mask is None and hidden_states.is_cuda and hidden_states.dim() == 3 and ctx.dim() == 3
             and _out_features(self.to_q) % heads == 0):
         shape = (hidden_states.shape[0], hidden_states.shape[1], ctx.shape[1], heads, _out_features(self.to_q) // heads,
-                 _compute_dtype(hidden_states))
+                 cdtype)
         if nat.attn_ctx_supported(*shape):      # up to 128 keys: the whole K/V of a head in LDS, one tile
             core = ctx_attention
         elif nat.attn_flash_supported(*shape):  # any length: online softmax over key tiles
             core = flash_attention
     if core is None:
         return original(hidden_states, *args, **kwargs)
-    q, k, v = self.to_q(hidden_states), self.to_k(ctx), self.to_v(ctx)
-    if q.dtype != k.dtype:  # mixed module dtypes outside autocast: compute in the query's dtype
-        k, v = k.to(q.dtype), v.to(q.dtype)
     scale = getattr(self, "scale", None)
-    out = core(q, k, v, heads, float(scale) if isinstance(scale, (int, float)) else None)
+    scale = float(scale) if isinstance(scale, (int, float)) else None
+    # Grouped LoRA projections (set up by trainer.LoraSlab.enable_groups): q/k/v of a self-attention in one launch each
+    # way, K/V of all cross-attentions over the same context in one launch per pass — the cores then work on column
+    # slices of the shared buffers (groups.py).
+    qkv = self.__dict__.get("_dfa_qkv")
+    kvg = self.__dict__.get("_dfa_ctx")
+    if self_attention and qkv is not None and qkv.usable(hidden_states, cdtype) and nat.attn_flash_supported(*shape):
+        from .groups import qkv_self_attention
+
+        out = qkv_self_attention(qkv, hidden_states, heads, scale, cdtype)
+    elif not self_attention and kvg is not None and core is ctx_attention and kvg[0].usable(ctx, cdtype):
+        from .groups import ctx_cross_attention
+
+        out = ctx_cross_attention(kvg[0], kvg[1], self.to_q(hidden_states), ctx, heads, scale, cdtype)
+    else:
+        q, k, v = self.to_q(hidden_states), self.to_k(ctx), self.to_v(ctx)
+        if q.dtype != k.dtype:  # mixed module dtypes outside autocast: compute in the query's dtype
+            k, v = k.to(q.dtype), v.to(q.dtype)
+        out = core(q, k, v, heads, scale)
     for layer in self.to_out:  # linear (LoRA target), dropout
         out = layer(out)
     return out

@@ -109,7 +109,8 @@ __device__ __forceinline__ void softmax_rows(f32x4 (&s)[NKF], int lq, int Tk, fl
 template <typename T, int KS, int DF, int NKF>
 __global__ __launch_bounds__(256) void attn_ctx_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
                                                             const T* __restrict__ V, T* __restrict__ O, int Tq, int Tk,
-                                                            int H, int d, float scale_log2e, int rq, int chunks) {
+                                                            int H, int d, float scale_log2e, int rq, int chunks,
+                                                            int64_t ldk) {
     using S = CtxShape<KS, DF, NKF>;
     using F8 = typename Mma<T>::F8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -125,8 +126,8 @@ __global__ __launch_bounds__(256) void attn_ctx_fwd_kernel(const T* __restrict__
 
     {
         StageRegs<T, KS, DF, NKF> kr, vr;  // both tensors in flight before the first LDS write
-        kr.load(K + (int64_t)b * Tk * HD + h * d, HD, Tk, d);
-        vr.load(V + (int64_t)b * Tk * HD + h * d, HD, Tk, d);
+        kr.load(K + (int64_t)b * Tk * ldk + h * d, ldk, Tk, d);  // K/V may be column slices of a wider buffer
+        vr.load(V + (int64_t)b * Tk * ldk + h * d, ldk, Tk, d);
         kr.store_rows(Ks);
         vr.store_transposed(Vt, 0);
     }
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256) void attn_ctx_bwd_kernel(const T* __restrict__
                                                             const T* __restrict__ V, const T* __restrict__ dO,
                                                             T* __restrict__ dQ, float* __restrict__ part, int Tq,
                                                             int Tk, int H, int d, float scale, float scale_log2e,
-                                                            int rq, int chunks) {
+                                                            int rq, int chunks, int64_t ldk) {
     using S = CtxShape<KS, DF, NKF>;
     using F8 = typename Mma<T>::F8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -222,8 +223,8 @@ __global__ __launch_bounds__(256) void attn_ctx_bwd_kernel(const T* __restrict__
 
     {
         StageRegs<T, KS, DF, NKF> kr, vr;
-        kr.load(K + (int64_t)b * Tk * HD + h * d, HD, Tk, d);
-        vr.load(V + (int64_t)b * Tk * HD + h * d, HD, Tk, d);
+        kr.load(K + (int64_t)b * Tk * ldk + h * d, ldk, Tk, d);  // K/V may be column slices of a wider buffer
+        vr.load(V + (int64_t)b * Tk * ldk + h * d, ldk, Tk, d);
         kr.store_rows(Ks);
         kr.store_transposed(Kt, c0);
         vr.store_rows(Vs);
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(256) void attn_ctx_bwd_kernel(const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void attn_ctx_reduce_kernel(const float* __restrict__ part, T* __restrict__ dK,
                                                                T* __restrict__ dV, int B, int Tk, int H, int d,
-                                                               int chunks, int slices, int NK, int DV) {
+                                                               int chunks, int slices, int NK, int DV, int64_t ld_dk) {
     const int64_t total = (int64_t)B * Tk * H * d;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % d);
@@ -400,8 +401,9 @@ __global__ __launch_bounds__(256) void attn_ctx_reduce_kernel(const float* __res
             sk += p[(int64_t)ch * slices * 2 * NK * DV];
             sv += p[(int64_t)ch * slices * 2 * NK * DV + NK * DV];
         }
-        dK[i] = from_f32<T>(sk);
-        dV[i] = from_f32<T>(sv);
+        const int64_t o = ((int64_t)b * Tk + key) * ld_dk + (int64_t)h * d + c;
+        dK[o] = from_f32<T>(sk);
+        dV[o] = from_f32<T>(sv);
     }
 }
 
@@ -454,6 +456,7 @@ struct CtxArgs {
     float* part;
     int B, Tq, Tk, H, d;
     float scale;
+    int64_t ldk, ld_dk;  // row strides (elements) of K/V and of dK/dV
 };
 
 template <typename T, int KS, int DF, int NKF, bool BWD>
@@ -469,7 +472,7 @@ int launch_ctx(const CtxArgs& a, const CtxPlan& pl, hipStream_t stream) {
             if (attr != hipSuccess) return LORA_E_LAUNCH;
         }
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, static_cast<const T*>(a.Q), static_cast<const T*>(a.K),
-                           static_cast<const T*>(a.V), static_cast<T*>(a.O), a.Tq, a.Tk, a.H, a.d, l2e, pl.rq, pl.chunks);
+                           static_cast<const T*>(a.V), static_cast<T*>(a.O), a.Tq, a.Tk, a.H, a.d, l2e, pl.rq, pl.chunks, a.ldk);
         LORA_LAUNCH_CHECK();
         return LORA_OK;
     } else {
@@ -483,12 +486,12 @@ int launch_ctx(const CtxArgs& a, const CtxPlan& pl, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3(grid.x, (unsigned)pl.slices), dim3(256), lds, stream, static_cast<const T*>(a.Q),
                        static_cast<const T*>(a.K), static_cast<const T*>(a.V), static_cast<const T*>(a.dO),
                        static_cast<T*>(a.dQ), a.part, a.Tq,
-                       a.Tk, a.H, a.d, a.scale, l2e, pl.rq, pl.chunks);
+                       a.Tk, a.H, a.d, a.scale, l2e, pl.rq, pl.chunks, a.ldk);
     LORA_LAUNCH_CHECK();
     const int64_t total = (int64_t)a.B * a.Tk * a.H * a.d;
     const unsigned blocks = (unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
     hipLaunchKernelGGL(attn_ctx_reduce_kernel<T>, dim3(blocks), dim3(256), 0, stream, a.part, static_cast<T*>(a.dK),
-                       static_cast<T*>(a.dV), a.B, a.Tk, a.H, a.d, pl.chunks, pl.slices, NKF * 16, DF * 16);
+                       static_cast<T*>(a.dV), a.B, a.Tk, a.H, a.d, pl.chunks, pl.slices, NKF * 16, DF * 16, a.ld_dk);
     LORA_LAUNCH_CHECK();
     return LORA_OK;
     }
@@ -535,23 +538,38 @@ extern "C" int64_t attn_ctx_bwd_workspace_bytes(int B, int Tq, int Tk, int H, in
     return (int64_t)B * H * pl.chunks * pl.slices * 2 * (pl.nkf * 16) * (pl.df * 16) * 4;
 }
 
-extern "C" int attn_ctx_fwd(const void* Q, const void* K, const void* V, void* O, int B, int Tq, int Tk, int H, int d,
-                            float scale, int dtype, void* stream) {
+extern "C" int attn_ctx_fwd_strided(const void* Q, const void* K, const void* V, void* O, int64_t ldk, int B, int Tq,
+                                    int Tk, int H, int d, float scale, int dtype, void* stream) {
     if (!Q || !K || !V || !O) return LORA_E_BADARG;
     if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || !aligned16(O)) return LORA_E_BADARG;
+    if (ldk < (int64_t)H * d || (ldk % 8) != 0) return LORA_E_BADARG;
     CtxArgs a{};
     a.Q = Q; a.K = K; a.V = V; a.O = O; a.B = B; a.Tq = Tq; a.Tk = Tk; a.H = H; a.d = d; a.scale = scale;
+    a.ldk = ldk; a.ld_dk = (int64_t)H * d;
     return run_ctx(a, false, dtype, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int attn_ctx_fwd(const void* Q, const void* K, const void* V, void* O, int B, int Tq, int Tk, int H, int d,
+                            float scale, int dtype, void* stream) {
+    return attn_ctx_fwd_strided(Q, K, V, O, (int64_t)H * d, B, Tq, Tk, H, d, scale, dtype, stream);
+}
+
+extern "C" int attn_ctx_bwd_strided(const void* Q, const void* K, const void* V, const void* dO, void* dQ, void* dK,
+                                    void* dV, void* workspace, int64_t ldk, int64_t ld_dk, int B, int Tq, int Tk, int H,
+                                    int d, float scale, int dtype, void* stream) {
+    if (!Q || !K || !V || !dO || !dQ || !dK || !dV || !workspace) return LORA_E_BADARG;
+    if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || !aligned16(dO) || !aligned16(dQ) || !aligned16(workspace))
+        return LORA_E_BADARG;
+    if (ldk < (int64_t)H * d || (ldk % 8) != 0 || ld_dk < (int64_t)H * d) return LORA_E_BADARG;
+    CtxArgs a{};
+    a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.dQ = dQ; a.dK = dK; a.dV = dV; a.part = static_cast<float*>(workspace);
+    a.B = B; a.Tq = Tq; a.Tk = Tk; a.H = H; a.d = d; a.scale = scale; a.ldk = ldk; a.ld_dk = ld_dk;
+    return run_ctx(a, true, dtype, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int attn_ctx_bwd(const void* Q, const void* K, const void* V, const void* dO, void* dQ, void* dK, void* dV,
                             void* workspace, int B, int Tq, int Tk, int H, int d, float scale, int dtype,
                             void* stream) {
-    if (!Q || !K || !V || !dO || !dQ || !dK || !dV || !workspace) return LORA_E_BADARG;
-    if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || !aligned16(dO) || !aligned16(dQ) || !aligned16(workspace))
-        return LORA_E_BADARG;
-    CtxArgs a{};
-    a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.dQ = dQ; a.dK = dK; a.dV = dV; a.part = static_cast<float*>(workspace);
-    a.B = B; a.Tq = Tq; a.Tk = Tk; a.H = H; a.d = d; a.scale = scale;
-    return run_ctx(a, true, dtype, static_cast<hipStream_t>(stream));
+    return attn_ctx_bwd_strided(Q, K, V, dO, dQ, dK, dV, workspace, (int64_t)H * d, (int64_t)H * d, B, Tq, Tk, H, d,
+                                scale, dtype, stream);
 }

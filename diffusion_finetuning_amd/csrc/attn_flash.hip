@@ -46,38 +46,44 @@ template <int KS, int DF> constexpr int flash_dkdv_lds_bytes() { return 4 * Flas
 template <typename T, int KS, int DF> struct TileStage {
     using S = FlashShape<KS, DF>;
     Chunk<T> a[S::IT], b[S::IT];
-    int64_t src[S::IT];           // element offset of the chunk inside tile 0
+    int64_t src[S::IT];           // element offset of the chunk inside tile 0 of A
+    int dld;                      // row stride of B minus row stride of A (uniform): B's offset = src + row·dld
     int row[S::IT], rowoff[S::IT], troff[S::IT];  // row; offset in a row-major [64][KROW] tile; in a transposed [DV][TROW] one
     bool have[S::IT];
-    __device__ __forceinline__ void init(int d, int64_t ld) {
+    __device__ __forceinline__ void init(int d, int64_t lda, int64_t ldb) {
         const int cpr = d >> 3, n = kTile * cpr;
+        dld = (int)(ldb - lda);
 #pragma unroll
         for (int i = 0; i < S::IT; ++i) {
             const int idx = threadIdx.x + i * 256;
             have[i] = idx < n;
             const int r = have[i] ? idx / cpr : 0, c = have[i] ? (idx - r * cpr) * 8 : 0;
             row[i] = r;
-            src[i] = (int64_t)r * ld + c;
+            src[i] = (int64_t)r * lda + c;
             rowoff[i] = r * S::KROW + c;
             troff[i] = c * S::TROW + key_pos(r);
         }
     }
-    // tile_off = first row of the tile × row stride; rows_valid >= 64 for a full tile
-    __device__ __forceinline__ void load(const T* A, const T* B, int64_t tile_off, int rows_valid) {
+    // A, B: first row of the tile in each tensor; rows_valid >= 64 for a full tile
+    __device__ __forceinline__ void load(const T* A, const T* B, int rows_valid) {
         if (rows_valid >= kTile) {
 #pragma unroll
             for (int i = 0; i < S::IT; ++i) {
-                const int64_t off = have[i] ? src[i] + tile_off : 0;
+                const int64_t off = have[i] ? src[i] : 0;
+                int rr = have[i] ? row[i] : 0;
+                asm volatile("" : "+v"(rr));  // recompute rr·dld at every tile: hoisted out of the loop it costs registers
                 a[i] = *reinterpret_cast<const Chunk<T>*>(A + off);
-                b[i] = *reinterpret_cast<const Chunk<T>*>(B + off);
+                b[i] = *reinterpret_cast<const Chunk<T>*>(B + off + rr * dld);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < S::IT; ++i) {
                 const bool ok = have[i] && row[i] < rows_valid;
-                const int64_t off = ok ? src[i] + tile_off : 0;
+                const int64_t off = ok ? src[i] : 0;
+                int rr = ok ? row[i] : 0;
+                asm volatile("" : "+v"(rr));
                 a[i] = load_or_zero<T>(A + off, ok);
-                b[i] = load_or_zero<T>(B + off, ok);
+                b[i] = load_or_zero<T>(B + off + rr * dld, ok);
             }
         }
     }
@@ -121,7 +127,7 @@ template <typename T, int KS, int DF, int RB>
 __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
                                                               const T* __restrict__ V, T* __restrict__ O,
                                                               float* __restrict__ LSE, int Tq, int Tk, int H, int d,
-                                                              float scale_log2e) {
+                                                              float scale_log2e, int64_t ldq) {
     using S = FlashShape<KS, DF>;
     using F8 = typename Mma<T>::F8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -133,16 +139,17 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restr
     const int64_t HD = (int64_t)H * d;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
-    const T* Qh = Q + (int64_t)b * Tq * HD + h * d;
-    const T* Kh = K + (int64_t)b * Tk * HD + h * d;
-    const T* Vh = V + (int64_t)b * Tk * HD + h * d;
+    // Q, K, V share the row stride ldq (they may be the three column slices of one grouped projection's output)
+    const T* Qh = Q + (int64_t)b * Tq * ldq + h * d;
+    const T* Kh = K + (int64_t)b * Tk * ldq + h * d;
+    const T* Vh = V + (int64_t)b * Tk * ldq + h * d;
 
     const int row0 = blockIdx.x * (64 * RB) + wave * (16 * RB);  // first query row of this wave
     F8 qf[RB][KS];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
         const int t = row0 + rb * 16 + l15;
-        load_row_frags<T, KS>(Qh + (int64_t)t * HD, Qh, t < Tq, d, lq, qf[rb]);
+        load_row_frags<T, KS>(Qh + (int64_t)t * ldq, Qh, t < Tq, d, lq, qf[rb]);
     }
     f32x4 o[RB][DF];
     float m[RB], l[RB];
@@ -157,8 +164,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restr
     lds_zero(smem, flash_fwd_lds_bytes<KS, DF>());
     __syncthreads();
     TileStage<T, KS, DF> stage;
-    stage.init(d, HD);
-    stage.load(Kh, Vh, 0, Tk);
+    stage.init(d, ldq, ldq);
+    stage.load(Kh, Vh, Tk);
     stage.store_a_rows(Ks);
     stage.store_b_transposed(Vt);
     __syncthreads();
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restr
         const int cur = kt & 1;
         const T* Kc = Ks + cur * S::K_HALFS;
         const T* Vc = Vt + cur * S::V_HALFS;
-        if (kt + 1 < n_tiles) stage.load(Kh, Vh, (int64_t)(kt + 1) * kTile * HD, Tk - (kt + 1) * kTile);  // in flight during this tile's work
+        if (kt + 1 < n_tiles) stage.load(Kh + (int64_t)(kt + 1) * kTile * ldq, Vh + (int64_t)(kt + 1) * kTile * ldq, Tk - (kt + 1) * kTile);  // in flight during this tile's work
 
         // ---- Sᵀ = K·Qᵀ: every K fragment read once, used for all RB row blocks -----------------
         f32x4 s[RB][kNKF];
@@ -301,7 +308,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const T* __restri
                                                              const T* __restrict__ V, const T* __restrict__ dO,
                                                              const float* __restrict__ LSE,
                                                              const float* __restrict__ Delta, T* __restrict__ dQ, int Tq,
-                                                             int Tk, int H, int d, float scale, float scale_log2e) {
+                                                             int Tk, int H, int d, float scale, float scale_log2e,
+                                                             int64_t ldq, int64_t ld_dq) {
     using S = FlashShape<KS, DF>;
     using F8 = typename Mma<T>::F8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -314,8 +322,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const T* __restri
     const int64_t HD = (int64_t)H * d;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
-    const T* Kh = K + (int64_t)b * Tk * HD + h * d;
-    const T* Vh = V + (int64_t)b * Tk * HD + h * d;
+    const T* Kh = K + (int64_t)b * Tk * ldq + h * d;
+    const T* Vh = V + (int64_t)b * Tk * ldq + h * d;
     const int row0 = blockIdx.x * (64 * RB) + wave * (16 * RB);
 
     F8 qf[RB][KS], gf[RB][KS];
@@ -326,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const T* __restri
         const int t = row0 + rb * 16 + l15;
         const bool valid = t < Tq;
         const int64_t roff = ((int64_t)b * Tq + t) * HD + h * d;
-        load_row_frags<T, KS>(Q + roff, Q, valid, d, lq, qf[rb]);
+        load_row_frags<T, KS>(Q + ((int64_t)b * Tq + t) * ldq + h * d, Q, valid, d, lq, qf[rb]);
         load_row_frags<T, KS>(dO + roff, dO, valid, d, lq, gf[rb]);
         lse[rb] = valid ? LSE[(int64_t)bh * Tq + t] : INFINITY;  // +inf: probability 0 for rows past the end
         delta[rb] = valid ? Delta[(int64_t)bh * Tq + t] : 0.f;
@@ -337,8 +345,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const T* __restri
     lds_zero(smem, flash_dq_lds_bytes<KS, DF>());
     __syncthreads();
     TileStage<T, KS, DF> stage;
-    stage.init(d, HD);
-    stage.load(Kh, Vh, 0, Tk);
+    stage.init(d, ldq, ldq);
+    stage.load(Kh, Vh, Tk);
     stage.store_a_rows(Ks);
     stage.store_b_rows(Vs);
     stage.store_a_transposed(Kt);
@@ -350,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const T* __restri
         const T* Kc = Ks + cur * S::K_HALFS;
         const T* Vc = Vs + cur * S::K_HALFS;
         const T* Ktc = Kt + cur * S::V_HALFS;
-        if (kt + 1 < n_tiles) stage.load(Kh, Vh, (int64_t)(kt + 1) * kTile * HD, Tk - (kt + 1) * kTile);
+        if (kt + 1 < n_tiles) stage.load(Kh + (int64_t)(kt + 1) * kTile * ldq, Vh + (int64_t)(kt + 1) * kTile * ldq, Tk - (kt + 1) * kTile);
 
         f32x4 s[RB][kNKF], dp[RB][kNKF];
 #pragma unroll
@@ -409,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const T* __restri
     for (int rb = 0; rb < RB; ++rb) {
         const int t = row0 + rb * 16 + l15;
         if (t >= Tq) continue;
-        T* grow = dQ + ((int64_t)b * Tq + t) * HD + h * d;
+        T* grow = dQ + ((int64_t)b * Tq + t) * ld_dq + h * d;
 #pragma unroll
         for (int df = 0; df < DF; ++df) {
             const int c = df * 16 + lq * 4;
@@ -449,7 +457,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
                                                                const float* __restrict__ LSE,
                                                                const float* __restrict__ Delta, T* __restrict__ dK,
                                                                T* __restrict__ dV, int Tq, int Tk, int H, int d,
-                                                               float scale, float scale_log2e) {
+                                                               float scale, float scale_log2e, int64_t ldq,
+                                                               int64_t ld_dq) {
     using S = FlashShape<KS, DF>;
     using F8 = typename Mma<T>::F8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -463,10 +472,10 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
     const int64_t HD = (int64_t)H * d;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
-    const T* Qh = Q + (int64_t)b * Tq * HD + h * d;
+    const T* Qh = Q + (int64_t)b * Tq * ldq + h * d;
     const T* Gh = dO + (int64_t)b * Tq * HD + h * d;
-    const T* Kh = K + (int64_t)b * Tk * HD + h * d;
-    const T* Vh = V + (int64_t)b * Tk * HD + h * d;
+    const T* Kh = K + (int64_t)b * Tk * ldq + h * d;
+    const T* Vh = V + (int64_t)b * Tk * ldq + h * d;
     const float* lse_h = LSE + (int64_t)bh * Tq;
     const float* delta_h = Delta + (int64_t)bh * Tq;
     const int key0 = blockIdx.x * (64 * NKW) + wave * (16 * NKW);  // first key of this wave
@@ -476,8 +485,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
 #pragma unroll
     for (int nf = 0; nf < NKW; ++nf) {
         const int key = key0 + nf * 16 + l15;
-        load_row_frags<T, KS>(Kh + (int64_t)key * HD, Kh, key < Tk, d, lq, kfr[nf]);
-        load_row_frags<T, KS>(Vh + (int64_t)key * HD, Vh, key < Tk, d, lq, vfr[nf]);
+        load_row_frags<T, KS>(Kh + (int64_t)key * ldq, Kh, key < Tk, d, lq, kfr[nf]);
+        load_row_frags<T, KS>(Vh + (int64_t)key * ldq, Vh, key < Tk, d, lq, vfr[nf]);
     }
     f32x4 dk[NKW][DF], dv[NKW][DF];  // lane = head-dim column l15 of fragment df; keys nf*16 + lq*4 + r
 #pragma unroll
@@ -489,8 +498,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
     __syncthreads();
     TileStage<T, KS, DF> stage;
     RowStats stats;
-    stage.init(d, HD);
-    stage.load(Qh, Gh, 0, Tq);
+    stage.init(d, ldq, HD);
+    stage.load(Qh, Gh, Tq);
     stats.load(lse_h, delta_h, 0, Tq);
     stage.store_a_rows(Qs);
     stage.store_b_rows(Gs);
@@ -504,7 +513,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
         const float* lc = lse_s + cur * 64;
         const float* dc = delta_s + cur * 64;
         if (qt + 1 < n_tiles) {
-            stage.load(Qh, Gh, (int64_t)(qt + 1) * 64 * HD, Tq - (qt + 1) * 64);
+            stage.load(Qh + (int64_t)(qt + 1) * 64 * ldq, Gh + (int64_t)(qt + 1) * 64 * HD, Tq - (qt + 1) * 64);
             stats.load(lse_h, delta_h, (qt + 1) * 64, Tq);
         }
         const bool keys_ragged = key0 + 16 * NKW > Tk;  // wave-uniform: only the last wave of the last workgroup
@@ -618,7 +627,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
             for (int r = 0; r < 4; ++r) {
                 const int key = key0 + nf * 16 + lq * 4 + r;
                 if (key < Tk && c < d) {
-                    const int64_t off = ((int64_t)b * Tk + key) * HD + h * d + c;
+                    const int64_t off = ((int64_t)b * Tk + key) * ld_dq + h * d + c;
                     dK[off] = from_f32<T>(dk[nf][df][r] * scale);
                     dV[off] = from_f32<T>(dv[nf][df][r]);
                 }
@@ -654,6 +663,7 @@ struct FlashArgs {
     float* LSE;
     int B, Tq, Tk, H, d;
     float scale;
+    int64_t ldq;  // row stride (elements) shared by Q, K and V
 };
 
 template <typename T, int KS, int DF, int RB>
@@ -668,7 +678,7 @@ int launch_flash_fwd(const FlashArgs& a, hipStream_t stream) {
     const dim3 grid((unsigned)((a.Tq + 64 * RB - 1) / (64 * RB)), (unsigned)(a.B * a.H));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, static_cast<const T*>(a.Q), static_cast<const T*>(a.K),
                        static_cast<const T*>(a.V), static_cast<T*>(a.O), a.LSE, a.Tq, a.Tk, a.H, a.d,
-                       a.scale * 1.4426950408889634f);
+                       a.scale * 1.4426950408889634f, a.ldq);
     LORA_LAUNCH_CHECK();
     return LORA_OK;
 }
@@ -692,6 +702,7 @@ struct FlashBwdArgs {
     float* delta;
     int B, Tq, Tk, H, d;
     float scale;
+    int64_t ldq, ld_dq;  // row strides shared by Q/K/V and by dQ/dK/dV
 };
 
 template <typename T, int KS, int DF, int RBQ, int NKW>
@@ -715,7 +726,8 @@ int launch_flash_bwd(const FlashBwdArgs& a, hipStream_t stream) {
         const dim3 grid((unsigned)((a.Tk + 64 * NKW - 1) / (64 * NKW)), (unsigned)(a.B * a.H));
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, static_cast<const T*>(a.Q), static_cast<const T*>(a.K),
                            static_cast<const T*>(a.V), static_cast<const T*>(a.dO), a.LSE, a.delta,
-                           static_cast<T*>(a.dK), static_cast<T*>(a.dV), a.Tq, a.Tk, a.H, a.d, a.scale, l2e);
+                           static_cast<T*>(a.dK), static_cast<T*>(a.dV), a.Tq, a.Tk, a.H, a.d, a.scale, l2e, a.ldq,
+                           a.ld_dq);
         LORA_LAUNCH_CHECK();
     }
     {
@@ -729,7 +741,7 @@ int launch_flash_bwd(const FlashBwdArgs& a, hipStream_t stream) {
         const dim3 grid((unsigned)((a.Tq + 64 * RBQ - 1) / (64 * RBQ)), (unsigned)(a.B * a.H));
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, static_cast<const T*>(a.Q), static_cast<const T*>(a.K),
                            static_cast<const T*>(a.V), static_cast<const T*>(a.dO), a.LSE, a.delta,
-                           static_cast<T*>(a.dQ), a.Tq, a.Tk, a.H, a.d, a.scale, l2e);
+                           static_cast<T*>(a.dQ), a.Tq, a.Tk, a.H, a.d, a.scale, l2e, a.ldq, a.ld_dq);
         LORA_LAUNCH_CHECK();
     }
     return LORA_OK;
@@ -749,16 +761,19 @@ int dispatch_flash_bwd(const FlashBwdArgs& a, const FlashPlan& pl, hipStream_t s
 
 extern "C" int64_t attn_flash_bwd_workspace_bytes(int B, int Tq, int H) { return (int64_t)B * H * Tq * 4; }
 
-extern "C" int attn_flash_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO,
-                              const float* LSE, void* dQ, void* dK, void* dV, void* workspace, int B, int Tq, int Tk,
-                              int H, int d, float scale, int dtype, void* stream) {
+extern "C" int attn_flash_bwd_strided(const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                                      const float* LSE, void* dQ, void* dK, void* dV, void* workspace, int64_t ldq,
+                                      int64_t ld_dq, int B, int Tq, int Tk, int H, int d, float scale, int dtype,
+                                      void* stream) {
     if (!Q || !K || !V || !O || !dO || !LSE || !dQ || !dK || !dV || !workspace) return LORA_E_BADARG;
     if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || !aligned16(O) || !aligned16(dO) || !aligned16(dQ) ||
-        !aligned16(workspace))
+        !aligned16(dK) || !aligned16(dV) || !aligned16(workspace))
         return LORA_E_BADARG;
+    const int64_t HD = (int64_t)H * d;
+    if (ldq < HD || ld_dq < HD || (ldq % 8) != 0 || (ld_dq % 8) != 0 || 64 * ldq > 0x7fffffffLL) return LORA_E_BADARG;
     FlashPlan pl;
     if (!plan_flash(B, Tq, Tk, H, d, &pl)) return LORA_E_BADARG;
-    FlashBwdArgs a{Q, K, V, O, dO, LSE, dQ, dK, dV, static_cast<float*>(workspace), B, Tq, Tk, H, d, scale};
+    FlashBwdArgs a{Q, K, V, O, dO, LSE, dQ, dK, dV, static_cast<float*>(workspace), B, Tq, Tk, H, d, scale, ldq, ld_dq};
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (dtype) {
         case LORA_F16: return dispatch_flash_bwd<half_t>(a, pl, s);
@@ -767,22 +782,35 @@ extern "C" int attn_flash_bwd(const void* Q, const void* K, const void* V, const
     }
 }
 
+extern "C" int attn_flash_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                              const float* LSE, void* dQ, void* dK, void* dV, void* workspace, int B, int Tq, int Tk,
+                              int H, int d, float scale, int dtype, void* stream) {
+    return attn_flash_bwd_strided(Q, K, V, O, dO, LSE, dQ, dK, dV, workspace, (int64_t)H * d, (int64_t)H * d, B, Tq,
+                                  Tk, H, d, scale, dtype, stream);
+}
+
 extern "C" int attn_flash_supported(int B, int Tq, int Tk, int H, int d, int dtype) {
     FlashPlan pl;
     return (dtype == LORA_F16 || dtype == LORA_BF16) && plan_flash(B, Tq, Tk, H, d, &pl) ? 1 : 0;
 }
 
-extern "C" int attn_flash_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int Tq, int Tk,
-                              int H, int d, float scale, int dtype, void* stream) {
+extern "C" int attn_flash_fwd_strided(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t ldq,
+                                      int B, int Tq, int Tk, int H, int d, float scale, int dtype, void* stream) {
     if (!Q || !K || !V || !O) return LORA_E_BADARG;
     if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || !aligned16(O)) return LORA_E_BADARG;
+    if (ldq < (int64_t)H * d || (ldq % 8) != 0 || 64 * ldq > 0x7fffffffLL) return LORA_E_BADARG;
     FlashPlan pl;
     if (!plan_flash(B, Tq, Tk, H, d, &pl)) return LORA_E_BADARG;
-    FlashArgs a{Q, K, V, O, LSE, B, Tq, Tk, H, d, scale};
+    FlashArgs a{Q, K, V, O, LSE, B, Tq, Tk, H, d, scale, ldq};
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (dtype) {
         case LORA_F16: return dispatch_flash_fwd<half_t>(a, pl, s);
         case LORA_BF16: return dispatch_flash_fwd<bf16_t>(a, pl, s);
         default: return LORA_E_BADARG;
     }
+}
+
+extern "C" int attn_flash_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int Tq, int Tk,
+                              int H, int d, float scale, int dtype, void* stream) {
+    return attn_flash_fwd_strided(Q, K, V, O, LSE, (int64_t)H * d, B, Tq, Tk, H, d, scale, dtype, stream);
 }

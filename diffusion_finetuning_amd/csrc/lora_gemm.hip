@@ -47,6 +47,15 @@ struct GemmParams {
     float scale;
     int tiles_m, tiles_n;
     int col_major;  // 1: consecutive tiles walk down M inside a column tile (an XCD then owns a slice of Bm)
+    int64_t lda;    // row stride of Am in elements (>= Kc: Am may be a column slice of a wider buffer)
+    // Grouped launches (several LoRA layers that share Am in one launch; nullptr = one layer):
+    //  MAIN:  tile_part[tn] = part | first << 16 for every column tile — the tile multiplies with the part's own
+    //         factor rows Fp + part·16·Kc, and the part's first tile writes P + part·M·r (column tiles never
+    //         straddle parts: the host picks BN accordingly);
+    // !MAIN:  part_table[g] = {column offset into Am, contraction length, element offset into Fp, float offset
+    //         into P} — blockIdx covers (row tile, part), every part contracts its own column range of Am.
+    const int* tile_part;
+    const int64_t* part_table;
 };
 
 constexpr int kRowBytes = 128;  // one K-step of one tile row
@@ -152,7 +161,8 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
     // every XCD a contiguous run of tiles; column tiles of one row panel are consecutive.
     // Pull every kernel argument into SGPRs now: one scalar-load round trip instead of two dependent ones.
     asm volatile("" ::"s"(p.Am), "s"(p.Bm), "s"(p.bias), "s"(p.Fp), "s"(p.Qp), "s"(p.C), "s"(p.P), "s"(p.M), "s"(p.Kc),
-                 "s"(p.Nc), "s"(p.scale), "s"(p.tiles_m), "s"(p.tiles_n), "s"(p.col_major));
+                 "s"(p.Nc), "s"(p.scale), "s"(p.tiles_m), "s"(p.tiles_n), "s"(p.col_major), "s"(p.lda), "s"(p.tile_part),
+                 "s"(p.part_table));
     int tile;
     {
         const int total = p.tiles_m * p.tiles_n;
@@ -175,6 +185,27 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
     const T* Ag = static_cast<const T*>(p.Am);
     const T* Bg = static_cast<const T*>(p.Bm);
     const T* Fg = static_cast<const T*>(p.Fp);
+    float* Pout = p.P;
+    int Kc = p.Kc;
+    bool write_p = p.P != nullptr && tn == 0;
+    if constexpr (MAIN) {
+        if (p.tile_part != nullptr) {
+            const int e = p.tile_part[tn];
+            const int part = e & 0xffff;
+            Fg += (int64_t)part * kRP * Kc;
+            if (Pout != nullptr) Pout += (int64_t)part * p.M * p.r;
+            write_p = p.P != nullptr && (e >> 16) != 0;
+        }
+    } else {
+        if (p.part_table != nullptr) {
+            const int64_t* e = p.part_table + (int64_t)tn * 4;
+            Ag += e[0];
+            Kc = (int)e[1];
+            Fg += e[2];
+            if (Pout != nullptr) Pout += e[3];
+            write_p = p.P != nullptr;
+        }
+    }
 
     // ---- staging addresses: thread = (row ld_row (+32·pass), 16-B chunk ld_chunk) ------------
     const int ld_chunk = tid & 7;
@@ -185,17 +216,17 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
     for (int i = 0; i < PA; ++i) {
         int64_t m = m0 + ld_row + RPP * i;
         if (m > p.M - 1) m = p.M - 1;  // clamp: rows past M are loaded from a valid row, never stored
-        a_ptr[i] = Ag + m * p.Kc;
+        a_ptr[i] = Ag + m * p.lda;
     }
     if constexpr (MAIN) {
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
             int n = n0 + ld_row + RPP * i;
             if (n > p.Nc - 1) n = p.Nc - 1;
-            b_ptr[i] = Bg + (int64_t)n * p.Kc;
+            b_ptr[i] = Bg + (int64_t)n * Kc;
         }
     }
-    const T* f_ptr = Fg + (int64_t)(ld_row & 15) * p.Kc;
+    const T* f_ptr = Fg + (int64_t)(ld_row & 15) * Kc;
 
     // ---- Q tile (epilogue factor): BN packed rows of 16 values, 16-B chunks, rows clamped at the edge -----
     if constexpr (MAIN) {
@@ -311,12 +342,12 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
         }
     };
 
-    const int nk = (p.Kc + BK - 1) / BK;
+    const int nk = (Kc + BK - 1) / BK;
     if constexpr (PIPE) {
         // ---- LDS-DMA ring.  Lane (row, physical chunk c') fetches logical chunk c' ^ (row & 7): the DMA
         // writes lane-linearly, so the swizzle lives on the source address and on the fragment reads.
         constexpr int L = PA + (MAIN ? PB : 0);  // DMA loads per lane per stage (+1 on the two factor-loading waves)
-        static_assert(kStages <= 3, "the counted wait below allows one newer stage in flight");
+        static_assert(kStages <= 6 && 4 * (L + 1) < 64, "counted waits cover up to four newer stages; vmcnt is a 6-bit field");
         const int src_off = (ld_chunk ^ (ld_row & 7)) * VEC;
         const int wave_rows = wave * 8 * kRowBytes;
         auto issue = [&](int kt, int buf) {
@@ -331,20 +362,35 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
             if (wave < 2) glds16(f_ptr + k0, st + OFF_F);
         };
         constexpr int DIST = kStages - 1;  // K-steps in flight ahead of the one being multiplied
-        issue(0, 0);
-        if (DIST > 1 && nk > 1) issue(1, 1);
+#pragma unroll
+        for (int i = 0; i < DIST; ++i)
+            if (i < nk) issue(i, i);
         STAMP(2);
         int buf = 0;
         for (int kt = 0; kt < nk; ++kt) {
-            // stage kt has landed for this wave once only the loads of the stages issued after it are outstanding
-            if (DIST > 1 && kt + 1 < nk) {
-                if (wave < 2) {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L + 1) : "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
-                }
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // stage kt has landed for this wave once only the loads of the stages issued after it are outstanding:
+            // `ahead` of them, L loads each (L + 1 on the two waves that also fetch the factor rows)
+            const int left = nk - 1 - kt;
+            const int ahead = left < DIST - 1 ? left : DIST - 1;
+            const bool fw = wave < 2;
+            switch (ahead) {
+                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                case 1:
+                    if (fw) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L + 1) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+                    break;
+                case 2:
+                    if (fw) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (L + 1)) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L) : "memory");
+                    break;
+                case 3:
+                    if (fw) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (L + 1)) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * L) : "memory");
+                    break;
+                default:
+                    if (fw) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (L + 1)) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * L) : "memory");
+                    break;
             }
             __builtin_amdgcn_s_barrier();  // every wave's part of stage kt is in; stage kt-1 is fully read
             if (kt == 0) STAMP(3);
@@ -360,7 +406,7 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
         int staged_k = 0;
         auto load_step = [&](int k0) {
             const int kc = k0 + ld_chunk * VEC;
-            const int kld = kc < p.Kc ? kc : p.Kc - VEC;  // Kc % VEC == 0 on this path
+            const int kld = kc < Kc ? kc : Kc - VEC;  // Kc % VEC == 0 on this path
             staged_k = kc;
 #pragma unroll
             for (int i = 0; i < PA; ++i) ra[i] = *reinterpret_cast<const Chunk<T>*>(a_ptr[i] + kld);
@@ -371,7 +417,7 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
             rfc = *reinterpret_cast<const Chunk<T>*>(f_ptr + kld);
         };
         auto store_step = [&]() {
-            if (staged_k >= p.Kc) {
+            if (staged_k >= Kc) {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
 #pragma unroll
@@ -413,7 +459,7 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
     }
     __syncthreads();
 
-    if (p.P != nullptr && tn == 0) {
+    if (write_p) {
         const int half = tid & 1;
         for (int row = tid >> 1; row < BM && m0 + row < p.M; row += NT / 2) {
 #pragma unroll
@@ -423,7 +469,7 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
                     float v = 0.f;
 #pragma unroll
                     for (int w = 0; w < WN; ++w) v += sP[(w * BM + row) * kSPS + j];
-                    p.P[(m0 + row) * p.r + j] = v;
+                    Pout[(m0 + row) * p.r + j] = v;
                 }
             }
         }
@@ -630,10 +676,32 @@ __global__ __launch_bounds__(256) void pack_factors_batched_kernel(const int64_t
                 blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
+// Generalised packing for grouped layers: one table row per FACTOR,
+//   {src_off, which (0: A [r,len] / 1: B [len,r]), len, r, d16_off, d16_ld, dT_off, rows}
+// writes rows j < `rows` of the [16,len] form at packed[d16_off + j·d16_ld + c] and/or columns j < `rows` of the [len,16]
+// form at packed[dT_off + c·16 + j] (an offset of -1 skips that form).  rows = 16 zero-fills the unused rank rows; a
+// block-diagonal group passes rows = r and pre-offset destinations so that every member fills only its own rank slots of
+// a buffer that was zeroed once.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_items_kernel(const int64_t* table, const float* params, T* packed) {
+    const int64_t* e = table + (int64_t)blockIdx.y * 8;
+    const float* src = params + e[0];
+    const int which = (int)e[1], len = (int)e[2], r = (int)e[3], rows = (int)e[7];
+    const int64_t d16 = e[4], ld16 = e[5], dT = e[6];
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < rows * len; idx += gridDim.x * 256) {
+        const int j = idx / len, c = idx - j * len;
+        const int jj = j < r ? j : r - 1;
+        const float v = which == 0 ? src[(int64_t)jj * len + c] : src[(int64_t)c * r + jj];
+        const T t = from_f32<T>(j < r ? v : 0.f);
+        if (d16 >= 0) packed[d16 + (int64_t)j * ld16 + c] = t;
+        if (dT >= 0) packed[dT + (int64_t)c * kRP + j] = t;
+    }
+}
+
 template <typename T, int BM, int BN, bool MAIN, int STG, int NW = 4>
 int launch_tile(GemmParams p, hipStream_t stream) {
     p.tiles_m = (int)((p.M + BM - 1) / BM);
-    p.tiles_n = MAIN ? (p.Nc + BN - 1) / BN : 1;
+    p.tiles_n = MAIN ? (p.Nc + BN - 1) / BN : (p.part_table ? p.tiles_n : 1);  // skinny grouped: tiles_n = parts
     static const int order_env = [] { const char* e = getenv("LORA_FORCE_COLMAJOR"); return e ? atoi(e) : -1; }();
     p.col_major = order_env >= 0 ? order_env : (MAIN && (int64_t)p.Nc > p.M ? 1 : 0);
     constexpr int lds = gemm_lds_bytes<BM, BN, T, MAIN, STG, NW>();
@@ -670,12 +738,16 @@ int forced_tile() {  // tuning knob for tools/gemm_bench.py only
 template <typename T, bool MAIN>
 int launch_pipe(const GemmParams& p, hipStream_t stream) {
     if (!MAIN) return launch_tile<T, 64, 64, false, 3>(p, stream);
+    static const int stg_env = [] { const char* e = getenv("LORA_FORCE_STAGES"); return e ? atoi(e) : 0; }();
+    if (p.tile_part != nullptr) {  // grouped: 64-wide column tiles never straddle two parts
+        const int64_t t64 = ((p.M + 63) / 64) * ((p.Nc + 63) / 64);
+        return t64 < 512 ? launch_tile<T, 64, 64, true, 3>(p, stream) : launch_tile<T, 64, 64, true, 2>(p, stream);
+    }
     const int64_t tiles128 = ((p.M + 127) / 128) * ((p.Nc + 127) / 128);
     const int64_t tiles64 = ((p.M + 63) / 64) * ((p.Nc + 63) / 64);
     const int padded = (p.Nc + 127) / 128 * 128;
     bool big = tiles128 >= 128 && (padded - p.Nc) * 4 <= p.Nc;
     bool deep = tiles64 < 512;
-    static const int stg_env = [] { const char* e = getenv("LORA_FORCE_STAGES"); return e ? atoi(e) : 0; }();
     if (forced_tile() == 0) big = true;
     if (forced_tile() == 2) big = false;
     static const int nw_env = [] { const char* e = getenv("LORA_FORCE_WAVES"); return e ? atoi(e) : 0; }();
@@ -685,7 +757,18 @@ int launch_pipe(const GemmParams& p, hipStream_t stream) {
     }
     if (stg_env == 2) deep = false;
     if (stg_env == 3) deep = true;
-    return deep ? launch_tile<T, 64, 64, true, 3>(p, stream) : launch_tile<T, 64, 64, true, 2>(p, stream);
+    // long contractions on grids that leave at most ~1 workgroup per CU: only prefetch depth hides the L2/HBM latency
+    // of each K-step there (4 stages = 2 workgroups per CU, 6 stages = 1)
+    const int nk = (p.Kc * (int)sizeof(T) + kRowBytes - 1) / kRowBytes;
+    int ring = deep ? 3 : 2;
+    if (deep && nk >= 8) ring = tiles64 <= 256 ? 6 : 4;
+    if (stg_env == 4 || stg_env == 6) ring = stg_env;
+    switch (ring) {
+        case 6: return launch_tile<T, 64, 64, true, 6>(p, stream);
+        case 4: return launch_tile<T, 64, 64, true, 4>(p, stream);
+        case 3: return launch_tile<T, 64, 64, true, 3>(p, stream);
+        default: return launch_tile<T, 64, 64, true, 2>(p, stream);
+    }
 }
 
 struct CallArgs {  // what an entry point knows
@@ -703,22 +786,32 @@ struct CallArgs {  // what an entry point knows
     int64_t M;
     int Kc, Nc, r;
     float scale;
+    int64_t lda;               // 0 = Kc
+    const int* tile_part;      // grouped MAIN launch
+    const int64_t* part_table; // grouped skinny launch
+    int n_parts;
+    bool packed_only;          // no fp32 masters behind Fp/Qp: the shape-agnostic kernels cannot run
 };
 
 template <typename T>
 int launch_typed(const CallArgs& c, bool main_part, hipStream_t stream) {
     constexpr int VEC = ElemTraits<T>::kVec;
     constexpr int BK = kRowBytes / (int)sizeof(T);
-    const bool fast = c.r <= kRP && c.Fp != nullptr && c.Qp != nullptr && (c.Kc % VEC) == 0 && aligned16(c.Am) &&
-                      aligned16(c.Fp) && aligned16(c.Qp) &&
+    const int64_t lda = c.lda > 0 ? c.lda : c.Kc;
+    const bool grouped = c.tile_part != nullptr || c.part_table != nullptr;
+    const bool fast = c.r <= kRP && c.Fp != nullptr && (c.Qp != nullptr || !main_part) && (c.Kc % VEC) == 0 &&
+                      (lda % VEC) == 0 && aligned16(c.Am) && aligned16(c.Fp) && aligned16(c.Qp) &&
                       (!main_part || ((c.Nc % VEC) == 0 && aligned16(c.Bm) && aligned16(c.C)));
     if (fast) {
         GemmParams p{};
         p.Am = c.Am; p.Bm = c.Bm; p.bias = c.bias; p.Fp = c.Fp; p.Qp = c.Qp;
         p.C = c.C; p.P = c.P; p.M = c.M; p.Kc = c.Kc; p.Nc = c.Nc; p.r = c.r; p.scale = c.scale;
+        p.lda = lda; p.tile_part = c.tile_part; p.part_table = c.part_table; p.tiles_n = c.n_parts;
         if ((c.Kc % BK) == 0) return main_part ? launch_pipe<T, true>(p, stream) : launch_pipe<T, false>(p, stream);
+        if (grouped) return LORA_E_UNSUPPORTED;  // grouped launches exist only on the LDS-DMA path
         return main_part ? launch_tile<T, 64, 64, true, 0>(p, stream) : launch_tile<T, 64, 64, false, 0>(p, stream);
     }
+    if (grouped || c.packed_only || lda != c.Kc) return LORA_E_UNSUPPORTED;
     GenericParams g{};
     g.Am = c.Am; g.Bm = c.Bm; g.bias = c.bias; g.F = c.F; g.f_sr = c.f_sr; g.f_sk = c.f_sk; g.Q = c.Q;
     g.q_sn = c.q_sn; g.q_sj = c.q_sj; g.C = c.C; g.P = c.P; g.M = c.M; g.Kc = c.Kc; g.Nc = c.Nc; g.r = c.r;
@@ -820,6 +913,29 @@ extern "C" int lora_pack_factors_batched(const int64_t* table, int n_layers, int
     return LORA_OK;
 }
 
+extern "C" int lora_pack_items(const int64_t* table, int n_items, int max_len, const float* params, void* packed,
+                               int dtype, void* stream) {
+    if (!table || !params || !packed || n_items < 1 || max_len < 1) return LORA_E_BADARG;
+    dim3 grid((unsigned)((kRP * max_len + 255) / 256 > 64 ? 64 : (kRP * max_len + 255) / 256), n_items);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case LORA_F32:
+            hipLaunchKernelGGL(pack_items_kernel<float>, grid, dim3(256), 0, s, table, params, static_cast<float*>(packed));
+            break;
+        case LORA_F16:
+            hipLaunchKernelGGL(pack_items_kernel<half_t>, grid, dim3(256), 0, s, table, params,
+                               static_cast<half_t*>(packed));
+            break;
+        case LORA_BF16:
+            hipLaunchKernelGGL(pack_items_kernel<bf16_t>, grid, dim3(256), 0, s, table, params,
+                               static_cast<bf16_t*>(packed));
+            break;
+        default: return LORA_E_BADARG;
+    }
+    LORA_LAUNCH_CHECK();
+    return LORA_OK;
+}
+
 extern "C" int lora_linear_fwd(const void* X, const void* W, const void* bias, const float* A, const float* B,
                                const void* Apack, const void* Bpack, void* Y, float* T_out, int64_t M, int K, int N,
                                int r, float scale, int dtype, void* stream) {
@@ -867,4 +983,28 @@ extern "C" int lora_linear_bwd_input(const void* dY, const void* Wt, const float
     const double flops = dX ? 2.0 * M * K * N + 2.0 * M * r * (double)(K + N) : 2.0 * M * r * (double)N;
     ProfWork work(bytes, flops);
     return launch_gemm(c, dX != nullptr, dtype, s);
+}
+
+extern "C" int lora_gemm_packed(const void* Am, int64_t lda, const void* Bm, const void* bias, const void* Fp,
+                                const void* Qp, const int* tile_part, const int64_t* part_table, int n_parts, void* C,
+                                float* P_out, int64_t M, int Kc, int Nc, int r, float scale, int64_t work_cols,
+                                int dtype, void* stream) {
+    if (M < 0 || Kc <= 0 || r < 1 || r > kRP) return LORA_E_BADARG;
+    if (dtype != LORA_F32 && dtype != LORA_F16 && dtype != LORA_BF16) return LORA_E_BADARG;
+    if (M == 0) return LORA_OK;
+    const bool main_part = C != nullptr;
+    if (!Am || !Fp || (main_part && (!Bm || !Qp || Nc <= 0))) return LORA_E_BADARG;
+    if (tile_part && !main_part) return LORA_E_BADARG;
+    if (part_table && (main_part || n_parts < 1)) return LORA_E_BADARG;
+    CallArgs c{};
+    c.Am = Am; c.Bm = Bm; c.bias = bias; c.Fp = Fp; c.Qp = Qp; c.C = C; c.P = P_out;
+    c.M = M; c.Kc = Kc; c.Nc = main_part ? Nc : 1; c.r = r; c.scale = scale; c.lda = lda;
+    c.tile_part = tile_part; c.part_table = part_table; c.n_parts = n_parts; c.packed_only = true;
+    const double e = esize(dtype);
+    const double kc = work_cols > 0 ? (double)work_cols : (double)Kc;
+    ProfWork work(main_part ? e * ((double)M * Kc + (double)Nc * Kc + (double)M * Nc) + e * r * (double)(Kc + Nc) +
+                                  (bias ? e * Nc : 0.0)
+                            : e * (double)M * kc + e * r * kc,
+                  main_part ? 2.0 * M * (double)Kc * Nc + 2.0 * M * r * (double)(Kc + Nc) : 2.0 * M * r * kc);
+    return launch_gemm(c, main_part, dtype, static_cast<hipStream_t>(stream));
 }

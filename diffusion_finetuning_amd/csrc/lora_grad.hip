@@ -3,57 +3,73 @@
 // — the autograd of lora_diffusion/lora.py:49-50 restricted to the parameters that
 // lora.py:179-180 mark trainable.  Both are  G[c,j] = s·Σ_m S[m,c]·P[m,j]  with a streamed
 // operand S ∈ {dY, X} read exactly once, so this is an HBM-streaming kernel:
-//   - a thread owns one 16-byte column chunk (8 halfs / 4 floats) and walks rows, UNROLL rows per trip so
-//     several independent loads are in flight; r×VEC fp32 accumulators stay in VGPRs; the P row is a
-//     broadcast load;
+//   - a thread owns one 16-byte column chunk (8 halfs / 4 floats) and walks rows, several rows per trip so
+//     that independent loads are in flight; r×VEC fp32 accumulators stay in VGPRs; the P row is a broadcast load;
 //   - 256 threads cover ⌊256/CL⌋ rows per pass when the strip is narrower than the workgroup; the row
 //     groups are combined through LDS (16-B writes, one summing thread per output);
-//   - the M range is cut into `n_blocks` row blocks; each block STORES its partial sums (plain 16-B-friendly
-//     stores, no global atomics: the outputs are only a few KB wide, and atomics from hundreds of
-//     workgroups onto so few cache lines serialise at the memory side);
-//   - lora_reduce_partials sums the row blocks in index order (deterministic) — one launch for the whole
-//     gradient slab of a model, or one per call in the plain autograd mode.
-// Both problems of a layer go out in ONE launch (blockIdx.z selects dY→gB or X→gA).
+//   - the M range is cut into row blocks; each block STORES its partial sums (plain stores, no global
+//     atomics: the outputs are only a few KB wide, and atomics from hundreds of workgroups onto so few
+//     cache lines serialise at the memory side); lora_fold_partials / lora_reduce_partials sum the row
+//     blocks in index order (deterministic).
+// A launch covers a TABLE of such problems that lives in the kernel-argument segment (≤ 28 problems per
+// launch, no device-side table to upload, safe to record into a hipGraph): a training step hands ALL its
+// 2×144 problems to lora_grad_batched at the end of backward — ~10 chip-filling launches instead of 144
+// latency-bound ones.  Operands may be strided views (a slice of a grouped projection's output) and the
+// rank columns of one problem may belong to several layers (grouped q/k/v: U is [M, 3r], three gA outputs).
 #include "common.h"
 
 namespace {
 
-struct GradProblem {
-    const void* S;    // [M, C]
-    const float* P;   // [M, r]
-    float* G;         // partial output of row block 0
-    int C;
-    int out_kn;       // 1: G is [r, C] (gA layout: j*C + c); 0: G is [C, r] (gB layout: c*r + j)
-    int CL;           // column chunks (threads) per row inside a strip
-    int strips;
-};
-struct GradParams {
-    GradProblem prob[2];
-    int64_t M;
+struct GradItem {       // 128 bytes
+    const void* S;      // [M, C] elements, row stride s_stride
+    const float* P;     // [M, r] fp32, row stride p_stride
+    float* out[4];      // partial output of row block 0 for rank group g = j / rg
+    int64_t s_stride;
     int64_t part_stride;  // floats between consecutive row blocks' partials
-    int r;
-    int rows_per_block;
+    int p_stride, C, r, rg;
+    int out_kn;         // 1: out is [rg, C] (gA layout: jl*C + c); 0: out is [C, rg] (gB layout: c*rg + jl)
+    int CL;             // column chunks (threads) per row inside a strip
+    int strips, rows_per_block;
+    int nb;
     float scale;
+    int64_t M;
+    int64_t pad_[2];
 };
+static_assert(sizeof(GradItem) == 128, "GradItem is laid out for the kernel-argument segment");
 
-constexpr int kUnroll = 8;
+constexpr int kItemsPerLaunch = 28;
+struct GradBatch {
+    GradItem item[kItemsPerLaunch];
+    int first_block[kItemsPerLaunch + 1];  // prefix sums of strips·nb
+    int n;
+};
+static_assert(sizeof(GradBatch) <= 4096, "kernel arguments are limited to 4 KB");
 
 template <typename T, int RP /* padded rank: 4, 8, 16 */>
-__global__ __launch_bounds__(256) void lora_grad_kernel(GradParams p) {
+__global__ __launch_bounds__(256) void lora_grad_kernel(const GradBatch p) {
     constexpr int VEC = ElemTraits<T>::kVec;
+    constexpr int UNROLL = RP >= 16 ? 4 : 8;  // rows in flight per thread (the P rows cost RP registers each)
     extern __shared__ __attribute__((aligned(16))) float sred[];
 
-    const GradProblem& q = p.prob[blockIdx.z];
-    if ((int)blockIdx.x >= q.strips) return;
+    // which problem does this workgroup belong to: linear scan of ≤ 28 prefix sums held in SGPRs
+    int it = 0;
+    for (int i = 1; i < p.n; ++i) it += ((int)blockIdx.x >= p.first_block[i]) ? 1 : 0;
+    it = __builtin_amdgcn_readfirstlane(it);
+    const GradItem& q = p.item[it];
+    const int local = blockIdx.x - p.first_block[it];
+    const int strip = local % q.strips;
+    const int rb = local / q.strips;
+
     const int tid = threadIdx.x;
     const int CL = q.CL;
     const int rows_pp = 256 / CL;  // rows per pass
     const int rsub = tid / CL;
     const int cg = tid - rsub * CL;
     const int c_local = cg * VEC;
-    const int c0 = blockIdx.x * CL * VEC;
+    const int c0 = strip * CL * VEC;
     const int stripW = min(CL * VEC, q.C - c0);
     const bool active = rsub < rows_pp && (c_local < stripW);
+    const int r = q.r;
 
     float acc[RP][VEC];
 #pragma unroll
@@ -61,32 +77,32 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(GradParams p) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[j][e] = 0.f;
 
-    const int64_t m_begin = (int64_t)blockIdx.y * p.rows_per_block;
-    int64_t m_end = m_begin + p.rows_per_block;
-    if (m_end > p.M) m_end = p.M;
+    const int64_t m_begin = (int64_t)rb * q.rows_per_block;
+    int64_t m_end = m_begin + q.rows_per_block;
+    if (m_end > q.M) m_end = q.M;
 
     if (active && m_begin < m_end) {
         const T* S = static_cast<const T*>(q.S) + c0 + c_local;
         const int64_t last = m_end - 1;
-        for (int64_t m = m_begin + rsub; m < m_end; m += (int64_t)rows_pp * kUnroll) {
-            // kUnroll independent rows per trip; loads are unconditional from clamped rows (a load under
+        for (int64_t m = m_begin + rsub; m < m_end; m += (int64_t)rows_pp * UNROLL) {
+            // UNROLL independent rows per trip; loads are unconditional from clamped rows (a load under
             // a per-lane condition is branched around and waited for one by one), tails are zero-weighted
-            Chunk<T> s[kUnroll];
-            float pv[kUnroll][RP];
+            Chunk<T> s[UNROLL];
+            float pv[UNROLL][RP];
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
+            for (int u = 0; u < UNROLL; ++u) {
                 const int64_t mu = m + (int64_t)u * rows_pp;
                 const int64_t ml = mu < m_end ? mu : last;
-                s[u] = *reinterpret_cast<const Chunk<T>*>(S + ml * q.C);
+                s[u] = *reinterpret_cast<const Chunk<T>*>(S + ml * q.s_stride);
 #pragma unroll
-                for (int j = 0; j < RP; ++j) pv[u][j] = q.P[ml * p.r + (j < p.r ? j : p.r - 1)];
+                for (int j = 0; j < RP; ++j) pv[u][j] = q.P[ml * q.p_stride + (j < r ? j : r - 1)];
             }
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
+            for (int u = 0; u < UNROLL; ++u) {
                 const bool ok = m + (int64_t)u * rows_pp < m_end;
 #pragma unroll
                 for (int j = 0; j < RP; ++j) {
-                    const float w = (ok && j < p.r) ? pv[u][j] : 0.f;
+                    const float w = (ok && j < r) ? pv[u][j] : 0.f;
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) acc[j][e] = fmaf(to_f32<T>(s[u].v[e]), w, acc[j][e]);
                 }
@@ -96,12 +112,12 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(GradParams p) {
 
     // combine the row groups through LDS, four rank columns at a time: image [row group][jj][strip column],
     // 16-B writes, then every output is summed over the row groups by one thread and stored (plain stores)
-    float* G = q.G + (int64_t)blockIdx.y * p.part_stride;
     const int WS = CL * VEC;
     const bool writer = rsub < rows_pp;
+    const int64_t part_off = (int64_t)rb * q.part_stride;
 #pragma unroll
     for (int j0 = 0; j0 < RP; j0 += 4) {
-        if (j0 < p.r) {  // wave-uniform
+        if (j0 < r) {  // wave-uniform
             __syncthreads();
             if (writer) {
 #pragma unroll
@@ -115,14 +131,16 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(GradParams p) {
             for (int i = tid; i < 4 * stripW; i += 256) {
                 const int jj = i / stripW, c = i - jj * stripW;
                 const int j = j0 + jj;
-                if (j < p.r) {
+                if (j < r) {
                     float sum = 0.f;
                     for (int g = 0; g < rows_pp; ++g) sum += sred[(g * 4 + jj) * WS + c];
-                    sum *= p.scale;
+                    sum *= q.scale;
+                    const int grp = j / q.rg, jl = j - grp * q.rg;
+                    float* G = q.out[grp] + part_off;
                     if (q.out_kn)
-                        G[(int64_t)j * q.C + c0 + c] = sum;       // gA[j, c]: contiguous runs per j
+                        G[(int64_t)jl * q.C + c0 + c] = sum;        // gA[j, c]: contiguous runs per j
                     else
-                        G[(int64_t)(c0 + c) * p.r + j] = sum;     // gB[c, j]
+                        G[(int64_t)(c0 + c) * q.rg + jl] = sum;     // gB[c, j]
                 }
             }
         }
@@ -130,20 +148,27 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(GradParams p) {
 }
 
 // Unaligned / large-rank path: one thread per output element, serial over the row block.  Correct, not fast.
+struct GenericGrad {
+    const void* S;
+    const float* P;
+    float* G;
+    int64_t M, part_stride;
+    int C, r, out_kn, rows_per_block;
+    float scale;
+};
 template <typename T>
-__global__ void lora_grad_generic_kernel(GradParams p) {
-    const GradProblem& q = p.prob[blockIdx.z];
+__global__ void lora_grad_generic_kernel(GenericGrad q) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)q.C * p.r) return;
-    const int c = (int)(idx / p.r), j = (int)(idx % p.r);
+    if (idx >= (int64_t)q.C * q.r) return;
+    const int c = (int)(idx / q.r), j = (int)(idx % q.r);
     const T* S = static_cast<const T*>(q.S);
-    const int64_t m_begin = (int64_t)blockIdx.y * p.rows_per_block;
-    int64_t m_end = m_begin + p.rows_per_block;
-    if (m_end > p.M) m_end = p.M;
+    const int64_t m_begin = (int64_t)blockIdx.y * q.rows_per_block;
+    int64_t m_end = m_begin + q.rows_per_block;
+    if (m_end > q.M) m_end = q.M;
     float s = 0.f;
-    for (int64_t m = m_begin; m < m_end; ++m) s = fmaf(to_f32<T>(S[m * q.C + c]), q.P[m * p.r + j], s);
-    float* G = q.G + (int64_t)blockIdx.y * p.part_stride;
-    (q.out_kn ? G[(int64_t)j * q.C + c] : G[idx]) = p.scale * s;
+    for (int64_t m = m_begin; m < m_end; ++m) s = fmaf(to_f32<T>(S[m * q.C + c]), q.P[m * q.r + j], s);
+    float* G = q.G + (int64_t)blockIdx.y * q.part_stride;
+    (q.out_kn ? G[(int64_t)j * q.C + c] : G[idx]) = q.scale * s;
 }
 
 // grads[i] (+)= Σ_b partials[b·stride + i], b ascending: deterministic.
@@ -167,46 +192,174 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* parti
     }
 }
 
+// The same fold for a table of slab ranges, each with its OWN block count (a layer with few rows wrote few
+// partials; nothing else is read): ranges[k] = {offset, length, blocks, 0} in floats, device memory.
+__global__ __launch_bounds__(256) void fold_partials_kernel(const int64_t* ranges, const float* partials, int64_t stride,
+                                                            float* grads, int accumulate) {
+    const int64_t* e = ranges + (int64_t)blockIdx.y * 4;
+    const int64_t off = e[0], n = e[1];
+    const int nb = (int)e[2];
+    const float* src = partials + off;
+    float* dst = grads + off;
+    if (((off | n) & 3) == 0) {
+        const int64_t nvec = n >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+            float4 s = accumulate ? reinterpret_cast<const float4*>(dst)[i] : float4{0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < nb; ++b) {
+                const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)b * stride + 4 * i);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            reinterpret_cast<float4*>(dst)[i] = s;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+            float s = accumulate ? dst[i] : 0.f;
+            for (int b = 0; b < nb; ++b) s += src[(int64_t)b * stride + i];
+            dst[i] = s;
+        }
+    }
+}
+
+// Row blocks and strips of one problem.  ~256 rows per block (at most 64 blocks): a block is then 80 KB … 1 MB of S,
+// a step's ~300 problems give several thousand workgroups, and the fold reads ≤ 64 partials per output.
+int plan_row_blocks(int64_t M) {
+    int64_t nb = M / 256;
+    if (nb < 1) nb = 1;
+    if (nb > LORA_GRAD_MAX_BLOCKS) nb = LORA_GRAD_MAX_BLOCKS;
+    return (int)nb;
+}
+
 template <typename T>
-int launch_grad(GradParams p, int n_blocks, hipStream_t stream) {
+bool plan_item(GradItem& q, int nb) {
     constexpr int VEC = ElemTraits<T>::kVec;
-    p.rows_per_block = (int)((p.M + n_blocks - 1) / n_blocks);
-    if (p.rows_per_block < 1) p.rows_per_block = 1;
-    bool fast = p.r <= 16;
-    for (int i = 0; i < 2; ++i) fast = fast && (p.prob[i].C % VEC) == 0 && aligned16(p.prob[i].S);
-    if (!fast) {
-        int cmax = p.prob[0].C > p.prob[1].C ? p.prob[0].C : p.prob[1].C;
-        const int64_t n = (int64_t)cmax * p.r;
-        hipLaunchKernelGGL(lora_grad_generic_kernel<T>, dim3((unsigned)((n + 255) / 256), n_blocks, 2), dim3(256), 0,
-                           stream, p);
-        LORA_LAUNCH_CHECK();
-        return LORA_OK;
-    }
-    const int rp = p.r <= 4 ? 4 : (p.r <= 8 ? 8 : 16);
+    if (q.C % VEC != 0 || !aligned16(q.S) || (q.s_stride % VEC) != 0) return false;
+    const int chunks = q.C / VEC;
     const int cl_cap = 256;  // a strip is at most one workgroup wide
-    int max_strips = 1, max_lds = 0;
-    for (int i = 0; i < 2; ++i) {
-        GradProblem& q = p.prob[i];
-        const int chunks = q.C / VEC;
-        // balance strips: smallest strip count that respects the cap, then even widths
-        const int strips = (chunks + cl_cap - 1) / cl_cap;
-        q.CL = (chunks + strips - 1) / strips;
-        q.strips = strips;
-        if (strips > max_strips) max_strips = strips;
-        const int lds = 256 * 4 * VEC * 4;  // [row groups][4][strip] floats, one 4-column slab at a time
-        if (lds > max_lds) max_lds = lds;
-    }
-    dim3 grid(max_strips, n_blocks, 2);
+    q.strips = (chunks + cl_cap - 1) / cl_cap;  // smallest strip count that respects the cap, then even widths
+    q.CL = (chunks + q.strips - 1) / q.strips;
+    q.nb = nb;
+    q.rows_per_block = (int)((q.M + nb - 1) / nb);
+    if (q.rows_per_block < 1) q.rows_per_block = 1;
+    return true;
+}
+
+template <typename T>
+int launch_batch(const GradBatch& b, int rp, hipStream_t stream) {
+    constexpr int VEC = ElemTraits<T>::kVec;
+    const int lds = 256 * 4 * VEC * 4;  // [row groups][4][strip] floats, one 4-column slab at a time
+    const dim3 grid((unsigned)b.first_block[b.n]);
     switch (rp) {
-        case 4: LORA_LAUNCH(PK_GRAD_R4, (lora_grad_kernel<T, 4>), grid, dim3(256), max_lds, stream, p); break;
-        case 8: LORA_LAUNCH(PK_GRAD_R8, (lora_grad_kernel<T, 8>), grid, dim3(256), max_lds, stream, p); break;
-        default: LORA_LAUNCH(PK_GRAD_R16, (lora_grad_kernel<T, 16>), grid, dim3(256), max_lds, stream, p); break;
+        case 4: LORA_LAUNCH(PK_GRAD_R4, (lora_grad_kernel<T, 4>), grid, dim3(256), lds, stream, b); break;
+        case 8: LORA_LAUNCH(PK_GRAD_R8, (lora_grad_kernel<T, 8>), grid, dim3(256), lds, stream, b); break;
+        default: LORA_LAUNCH(PK_GRAD_R16, (lora_grad_kernel<T, 16>), grid, dim3(256), lds, stream, b); break;
     }
     LORA_LAUNCH_CHECK();
     return LORA_OK;
 }
 
+template <typename T>
+int launch_generic(const lora_grad_problem& g, int nb, hipStream_t stream) {
+    if (g.rg != g.r || g.s_stride != g.C || g.p_stride != g.r) return LORA_E_UNSUPPORTED;
+    GenericGrad q{};
+    q.S = g.S; q.P = g.P; q.G = g.out[0]; q.M = g.M; q.part_stride = g.part_stride; q.C = g.C; q.r = g.r;
+    q.out_kn = g.out_kn; q.scale = g.scale;
+    q.rows_per_block = (int)((g.M + nb - 1) / nb);
+    if (q.rows_per_block < 1) q.rows_per_block = 1;
+    const int64_t n = (int64_t)g.C * g.r;
+    hipLaunchKernelGGL(lora_grad_generic_kernel<T>, dim3((unsigned)((n + 255) / 256), nb), dim3(256), 0, stream, q);
+    LORA_LAUNCH_CHECK();
+    return LORA_OK;
+}
+
+double problem_bytes(const lora_grad_problem& g, double e) {
+    return e * (double)g.M * g.C + 4.0 * (double)g.M * g.r + 4.0 * (double)g.r * g.C;
+}
+
+// Plans and launches `n` problems: rank classes (4 / 8 / 16 accumulator columns) go out separately, each in
+// chunks of ≤ 28 problems whose tables travel as kernel arguments.
+template <typename T>
+int run_problems(const lora_grad_problem* probs, int n, const int* n_blocks, hipStream_t stream) {
+    const double e = sizeof(T);
+    for (int cls = 0; cls < 3; ++cls) {
+        const int rp = cls == 0 ? 4 : (cls == 1 ? 8 : 16);
+        GradBatch b;
+        b.n = 0;
+        b.first_block[0] = 0;
+        double bytes = 0.0, flops = 0.0;
+        auto flush = [&]() -> int {
+            if (b.n == 0) return LORA_OK;
+            ProfWork work(bytes, flops);
+            const int st = launch_batch<T>(b, rp, stream);
+            b.n = 0;
+            bytes = flops = 0.0;
+            return st;
+        };
+        for (int i = 0; i < n; ++i) {
+            const lora_grad_problem& g = probs[i];
+            const int want = g.r <= 4 ? 4 : (g.r <= 8 ? 8 : 16);
+            if (g.r > 16) {
+                if (cls == 0) {
+                    const int st = launch_generic<T>(g, n_blocks[i], stream);
+                    if (st != LORA_OK) return st;
+                }
+                continue;
+            }
+            if (want != rp) continue;
+            GradItem q{};
+            q.S = g.S; q.P = g.P;
+            for (int k = 0; k < 4; ++k) q.out[k] = g.out[k];
+            q.s_stride = g.s_stride; q.part_stride = g.part_stride; q.p_stride = g.p_stride; q.C = g.C; q.r = g.r;
+            q.rg = g.rg; q.out_kn = g.out_kn; q.scale = g.scale; q.M = g.M;
+            if (!plan_item<T>(q, n_blocks[i])) {  // unaligned operand: the shape-agnostic kernel
+                const int st = launch_generic<T>(g, n_blocks[i], stream);
+                if (st != LORA_OK) return st;
+                continue;
+            }
+            b.item[b.n] = q;
+            b.first_block[b.n + 1] = b.first_block[b.n] + q.strips * q.nb;
+            ++b.n;
+            bytes += problem_bytes(g, e);
+            flops += 2.0 * (double)g.M * g.r * g.C;
+            if (b.n == kItemsPerLaunch) {
+                const int st = flush();
+                if (st != LORA_OK) return st;
+            }
+        }
+        const int st = flush();
+        if (st != LORA_OK) return st;
+    }
+    return LORA_OK;
+}
+
+int check_problem(const lora_grad_problem& g) {
+    if (g.M < 0 || g.C <= 0 || g.r < 1 || g.rg < 1 || g.rg > g.r || (g.r + g.rg - 1) / g.rg > 4) return LORA_E_BADARG;
+    if (g.M > 0 && (!g.S || !g.P)) return LORA_E_BADARG;
+    for (int k = 0; k < (g.r + g.rg - 1) / g.rg; ++k)
+        if (!g.out[k]) return LORA_E_BADARG;
+    return LORA_OK;
+}
+
 }  // namespace
+
+extern "C" int lora_grad_row_blocks(int64_t M) { return plan_row_blocks(M); }
+
+extern "C" int lora_grad_batched(const lora_grad_problem* problems, int n, int dtype, void* stream) {
+    if (!problems || n < 1) return LORA_E_BADARG;
+    if (n > 4096) return LORA_E_BADARG;
+    int nb[4096];
+    for (int i = 0; i < n; ++i) {
+        const int st = check_problem(problems[i]);
+        if (st != LORA_OK) return st;
+        nb[i] = problems[i].n_blocks > 0 ? problems[i].n_blocks : plan_row_blocks(problems[i].M);
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case LORA_F32: return run_problems<float>(problems, n, nb, s);
+        case LORA_F16: return run_problems<half_t>(problems, n, nb, s);
+        case LORA_BF16: return run_problems<bf16_t>(problems, n, nb, s);
+        default: return LORA_E_BADARG;
+    }
+}
 
 extern "C" int lora_linear_bwd_params(const void* dY, const void* X, const float* T, const float* U,
                                       float* gA_part, float* gB_part, int64_t part_stride, int n_blocks,
@@ -215,20 +368,16 @@ extern "C" int lora_linear_bwd_params(const void* dY, const void* X, const float
     if (r < 1 || r > (K < N ? K : N)) return LORA_E_RANK;
     if (!gA_part || !gB_part) return LORA_E_BADARG;
     if (M > 0 && (!dY || !X || !T || !U)) return LORA_E_BADARG;
-    GradParams p{};
-    p.prob[0].S = dY; p.prob[0].P = T; p.prob[0].G = gB_part; p.prob[0].C = N; p.prob[0].out_kn = 0;
-    p.prob[1].S = X;  p.prob[1].P = U; p.prob[1].G = gA_part; p.prob[1].C = K; p.prob[1].out_kn = 1;
-    p.M = M; p.r = r; p.scale = scale; p.part_stride = part_stride;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const double e = dtype == LORA_F32 ? 4.0 : 2.0;
-    ProfWork work(e * ((double)M * N + (double)M * K) + 4.0 * r * (double)(K + N) + 8.0 * M * r,
-                  2.0 * M * r * (double)(K + N));
-    switch (dtype) {
-        case LORA_F32: return launch_grad<float>(p, n_blocks, s);
-        case LORA_F16: return launch_grad<half_t>(p, n_blocks, s);
-        case LORA_BF16: return launch_grad<bf16_t>(p, n_blocks, s);
-        default: return LORA_E_BADARG;
+    lora_grad_problem pr[2] = {};
+    pr[0].S = dY; pr[0].P = T; pr[0].out[0] = gB_part; pr[0].s_stride = N; pr[0].p_stride = r; pr[0].C = N;
+    pr[0].out_kn = 0;
+    pr[1].S = X;  pr[1].P = U; pr[1].out[0] = gA_part; pr[1].s_stride = K; pr[1].p_stride = r; pr[1].C = K;
+    pr[1].out_kn = 1;
+    for (int i = 0; i < 2; ++i) {
+        pr[i].part_stride = part_stride; pr[i].M = M; pr[i].r = r; pr[i].rg = r; pr[i].scale = scale;
+        pr[i].n_blocks = n_blocks;
     }
+    return lora_grad_batched(pr, 2, dtype, stream);
 }
 
 extern "C" int lora_reduce_partials(const float* partials, int64_t part_stride, int n_blocks, float* grads,
@@ -240,6 +389,19 @@ extern "C" int lora_reduce_partials(const float* partials, int64_t part_stride, 
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                        partials, part_stride, n_blocks, grads, n, accumulate);
+    LORA_LAUNCH_CHECK();
+    return LORA_OK;
+}
+
+extern "C" int lora_fold_partials(const int64_t* ranges, int n_ranges, int64_t max_len, const float* partials,
+                                  int64_t part_stride, float* grads, int accumulate, void* stream) {
+    if (!ranges || !partials || !grads || n_ranges < 1 || max_len < 1) return LORA_E_BADARG;
+    if (!aligned16(partials) || !aligned16(grads) || (part_stride & 3)) return LORA_E_ALIGN;
+    int64_t bx = (max_len / 4 + 255) / 256;
+    if (bx > 64) bx = 64;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)bx, (unsigned)n_ranges), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), ranges, partials, part_stride, grads, accumulate);
     LORA_LAUNCH_CHECK();
     return LORA_OK;
 }

@@ -1,0 +1,340 @@
+"""Grouped LoRA projections: several `LoraInjectedLinear` modules that multiply the SAME input run as one launch.
+
+The reference calls every wrapped linear on its own (diffusers `CrossAttention.forward`: `self.to_q(x)`, `self.to_k(c)`,
+`self.to_v(c)`; lora_diffusion/lora.py:49-50 each).  Two groupings are free of any change in arithmetic:
+
+  * `QKVGroup`  — attn1 `to_q / to_k / to_v` of one transformer block share `x`: one fused forward on the concatenated
+    frozen weight `[Wq; Wk; Wv]` with a rank-3r block-diagonal factor, one fused dX on its transpose (no `dXq + dXk + dXv`
+    accumulation), and the attention core reads / writes the q | k | v column slices of ONE buffer in place.
+  * `CtxKVGroup` — attn2 `to_k / to_v` of ALL transformer blocks share `encoder_hidden_states`: one forward launch for the
+    32 projections of an SD UNet at the first cross-attention of a pass, one P-only backward launch at the end (the text
+    encoder output is frozen: no dX), the cross-attention cores read K / V (and write dK / dV) as column slices.
+
+Groups exist only under a `trainer.LoraSlab` (it owns the packed factors the fused kernels stream and collects the
+factor-gradient problems); without one every module keeps running on its own through `ops.lora_linear`.
+HIP device only, like the rest of the path.
+"""
+from typing import List, Optional, Sequence
+
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import _native as nat
+
+RANK_PAD = 16  # rank slots of one packed factor (kRP in csrc/lora_gemm.hip)
+
+
+def _cast_cat(weights: Sequence[torch.Tensor], cdtype: torch.dtype, transpose: bool) -> torch.Tensor:
+    parts = []
+    for w in weights:
+        wd = w.detach()
+        wd = wd if wd.is_contiguous() else wd.contiguous()
+        parts.append(wd if wd.dtype == cdtype else nat.lora_cast_matrix(wd, cdtype, False))
+    cat = torch.cat(parts, dim=0)
+    return nat.lora_cast_matrix(cat, cdtype, True) if transpose else cat
+
+
+class _FrozenCat:
+    """[W0; W1; ...] in the compute dtype (and its transpose), rebuilt when any member weight changes."""
+
+    def __init__(self, layers):
+        self.layers = layers
+        self._key = None
+        self._w = self._wt = None
+
+    def get(self, cdtype: torch.dtype, need_wt: bool):
+        ws = [l.linear.weight for l in self.layers]
+        key = tuple((w.data_ptr(), w._version, w.dtype, w.device) for w in ws) + (cdtype,)
+        if key != self._key:
+            self._key, self._w, self._wt = key, _cast_cat(ws, cdtype, False), None
+        if need_wt and self._wt is None:
+            self._wt = nat.lora_cast_matrix(self._w, cdtype, True)
+        return self._w, self._wt
+
+
+def _same_scale(layers) -> Optional[float]:
+    s = float(layers[0].scale)
+    return s if all(float(l.scale) == s for l in layers) else None
+
+
+class QKVGroup:
+    """to_q / to_k / to_v of one self-attention module.  Packed operands (views into the slab's packed buffer):
+         Fa [16,K]   rows g·r+j = A_g[j,:]           (forward main-loop factor)
+         Qb [3N,16]  row g·N+n, col g·r+j = B_g[n,j]  (forward epilogue factor, block diagonal)
+         Fb [16,3N]  row g·r+j, col g·N+n = B_g[n,j]  (backward main-loop factor, block diagonal)
+         Qa [K,16]   row k, col g·r+j = A_g[j,k]      (backward epilogue factor)"""
+
+    def __init__(self, layers, sinks):
+        self.layers, self.sinks = list(layers), list(sinks)
+        lin = layers[0].linear
+        self.K, self.N = lin.in_features, lin.out_features
+        self.r = layers[0].lora_down.weight.shape[0]
+        self.G = len(layers)
+        self.frozen = _FrozenCat(self.layers)
+        self.Fa = self.Qb = self.Fb = self.Qa = None  # set by LoraSlab.enable_packed
+
+    @staticmethod
+    def eligible(layers) -> bool:
+        from .core import LoraInjectedLinear
+
+        if not all(isinstance(l, LoraInjectedLinear) for l in layers):
+            return False
+        lin = layers[0].linear
+        r = layers[0].lora_down.weight.shape[0]
+        return (len(layers) * r <= RANK_PAD and lin.in_features % 64 == 0 and lin.out_features % 64 == 0 and
+                all(l.linear.in_features == lin.in_features and l.linear.out_features == lin.out_features and
+                    l.linear.bias is None and l.lora_down.weight.shape[0] == r for l in layers))
+
+    def usable(self, x: torch.Tensor, cdtype: torch.dtype) -> bool:
+        return (self.Fa is not None and self.Fa.dtype == cdtype and x.is_cuda and _same_scale(self.layers) is not None
+                and all(not l.linear.weight.requires_grad for l in self.layers))
+
+
+class _QKVProjFn(torch.autograd.Function):
+    """qkv[M, 3N] = x·[Wq;Wk;Wv]ᵀ + s·(x·A_catᵀ)·B_bdᵀ — three lora.py:49-50 forwards in one launch; backward = one fused
+    dX launch; the six factor gradients are handed to the slab's batched gradient launch."""
+
+    @staticmethod
+    def forward(ctx, x, group, cdtype, *factors):  # factors: the (down, up) Parameters, listed so autograd tracks them
+        K, N3, rr = group.K, group.G * group.N, group.G * group.r
+        x2 = x.reshape(-1, K)
+        if x2.dtype != cdtype:
+            x2 = x2.to(cdtype)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        need_wt = torch.is_grad_enabled() and x.requires_grad
+        w, wt = group.frozen.get(cdtype, need_wt)
+        M = x2.shape[0]
+        qkv = torch.empty((M, N3), dtype=cdtype, device=x2.device)
+        t = torch.empty((M, rr), dtype=torch.float32, device=x2.device)
+        scale = _same_scale(group.layers)
+        nat.lora_gemm_packed(x2, K, w, None, group.Fa, group.Qb, None, None, 0, qkv, t, M, K, N3, rr, scale)
+        ctx.save_for_backward(x2, t)
+        ctx.group, ctx.wt, ctx.scale = group, wt, scale
+        ctx.x_shape, ctx.x_dtype = x.shape, x.dtype
+        return qkv.view(*x.shape[:-1], N3)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dqkv):
+        g = ctx.group
+        x2, t = ctx.saved_tensors
+        K, N, N3, r, rr = g.K, g.N, g.G * g.N, g.r, g.G * g.r
+        d2 = dqkv.reshape(-1, N3)
+        if d2.dtype != x2.dtype:
+            d2 = d2.to(x2.dtype)
+        if not d2.is_contiguous():
+            d2 = d2.contiguous()
+        M = d2.shape[0]
+        need_dx = ctx.needs_input_grad[0]
+        u = torch.empty((M, rr), dtype=torch.float32, device=d2.device)
+        dx2 = None
+        if need_dx:
+            if ctx.wt is None:
+                raise RuntimeError("grouped q/k/v backward: Wᵀ operand was not prepared in forward")
+            dx2 = torch.empty((M, K), dtype=d2.dtype, device=d2.device)
+            nat.lora_gemm_packed(d2, N3, ctx.wt, None, g.Fb, g.Qa, None, None, 0, dx2, u, M, N3, K, rr, ctx.scale)
+        else:
+            nat.lora_gemm_packed(d2, N3, None, None, g.Fb, None, None, None, 0, None, u, M, N3, 0, rr, ctx.scale)
+        slab = g.sinks[0].slab
+        stride = slab.stride
+        for i, sink in enumerate(g.sinks):  # gB_i = s·dY_iᵀ·T_i : column slices of the shared buffers
+            slab.defer(nat.grad_problem(d2, i * N, N3, N, t, i * r, rr, r, [sink.up_ptr], r, False, stride, M, ctx.scale),
+                       sink.index, (d2, t))
+        # gA_cat = s·U_catᵀ·X, rank groups of r → the three `down` gradients, X read once
+        slab.defer(nat.grad_problem(x2, 0, K, K, u, 0, rr, rr, [s.down_ptr for s in g.sinks], r, True, stride, M, ctx.scale),
+                   None, (x2, u))
+        dx = None
+        if need_dx:
+            dx = dx2.view(ctx.x_shape)
+            if dx.dtype != ctx.x_dtype:
+                dx = dx.to(ctx.x_dtype)
+        return (dx, None, None) + (None,) * (2 * g.G)
+
+
+class _FlashQKVFn(torch.autograd.Function):
+    """Self-attention core on the q | k | v column slices of one [B,T,3·H·d] buffer; backward writes dq | dk | dv as the
+    column slices of one buffer — the dY of `_QKVProjFn`, no split / cat copies either way."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, scale):
+        q = qkv if qkv.is_contiguous() else qkv.contiguous()
+        need = ctx.needs_input_grad[0]
+        out, lse = nat.attn_flash_fwd_qkv(q, heads, scale, want_lse=need)
+        if need:
+            ctx.save_for_backward(q, out, lse)
+        ctx.heads, ctx.scale = heads, scale
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        q, out, lse = ctx.saved_tensors
+        return nat.attn_flash_bwd_qkv(q, out, dout if dout.is_contiguous() else dout.contiguous(), lse, ctx.heads,
+                                      ctx.scale), None, None
+
+
+def qkv_self_attention(group: QKVGroup, x: torch.Tensor, heads: int, scale: Optional[float], cdtype: torch.dtype):
+    """softmax(q kᵀ·scale) v for q, k, v = the group's three LoRA projections of x → [B, T, H·d]."""
+    factors = [p for l in group.layers for p in (l.lora_down.weight, l.lora_up.weight)]
+    qkv = _QKVProjFn.apply(x, group, cdtype, *factors)
+    if scale is None:
+        scale = (group.N // heads) ** -0.5
+    return _FlashQKVFn.apply(qkv, heads, float(scale))
+
+
+class _CtxPass:
+    """What one forward pass of the model shares between its cross-attention modules."""
+
+    def __init__(self, key, kv):
+        self.key, self.kv = key, kv
+        self.consumers = 0       # cross-attentions that took their K / V from `kv` in this pass
+        self.returned = 0        # ... whose backward has run
+        self.dkv = None          # gradient buffer, same layout as kv
+
+
+class CtxKVGroup:
+    """to_k / to_v of every cross-attention module that projects the same encoder_hidden_states.  Part 2i = to_k and
+    part 2i+1 = to_v of module i; columns [off[g], off[g] + N[g]) of the [M, ΣN] buffers belong to part g."""
+
+    def __init__(self, modules, layers, sinks):
+        self.modules, self.layers, self.sinks = list(modules), list(layers), list(sinks)
+        self.G = len(self.layers)
+        self.K = self.layers[0].linear.in_features
+        self.r = self.layers[0].lora_down.weight.shape[0]
+        self.N = [l.linear.out_features for l in self.layers]
+        self.off, o = [], 0
+        for n in self.N:
+            self.off.append(o)
+            o += n
+        self.total = o
+        self.frozen = _FrozenCat(self.layers)
+        self.A16 = self.B16 = self.Bt16 = None  # packed operands: set by LoraSlab.enable_packed
+        self.bt_off: List[int] = []              # element offset of part g's Bt16 [16, N_g] inside self.Bt16
+        self.tile_part = None
+        self._part_tables = {}
+        self._pass: Optional[_CtxPass] = None
+
+    @staticmethod
+    def eligible(layers) -> bool:
+        from .core import LoraInjectedLinear
+
+        if not layers or not all(isinstance(l, LoraInjectedLinear) for l in layers):
+            return False
+        k, r = layers[0].linear.in_features, layers[0].lora_down.weight.shape[0]
+        return (r <= RANK_PAD and k % 64 == 0 and
+                all(l.linear.in_features == k and l.linear.out_features % 64 == 0 and l.linear.bias is None and
+                    l.lora_down.weight.shape[0] == r for l in layers))
+
+    def new_pass(self):
+        self._pass = None
+
+    def usable(self, ctx_t: torch.Tensor, cdtype: torch.dtype) -> bool:
+        return (self.A16 is not None and self.A16.dtype == cdtype and ctx_t.is_cuda and ctx_t.dim() == 3 and
+                ctx_t.shape[-1] == self.K and not ctx_t.requires_grad and _same_scale(self.layers) is not None and
+                all(not l.linear.weight.requires_grad for l in self.layers))
+
+    def tables(self, device, M: int):
+        if self.tile_part is None:
+            tp = []
+            for g, n in enumerate(self.N):
+                tp += [g | (1 << 16)] + [g] * (n // 64 - 1)
+            self.tile_part = torch.tensor(tp, dtype=torch.int32).to(device)
+        pt = self._part_tables.get(M)
+        if pt is None:
+            rows = [[self.off[g], self.N[g], self.bt_off[g], g * M * self.r] for g in range(self.G)]
+            pt = self._part_tables[M] = torch.tensor(rows, dtype=torch.int64).to(device)
+        return self.tile_part, pt
+
+    def project(self, ctx_t: torch.Tensor, cdtype: torch.dtype) -> _CtxPass:
+        """The [B·L, ΣN] buffer of all K / V projections of `ctx_t`, computed by the first cross-attention of a pass."""
+        key = (ctx_t.data_ptr(), ctx_t._version, tuple(ctx_t.shape), ctx_t.dtype, torch.is_grad_enabled())
+        st = self._pass
+        if st is None or st.key != key:
+            factors = [p for l in self.layers for p in (l.lora_down.weight, l.lora_up.weight)]
+            st = self._pass = _CtxPass(key, None)
+            st.kv = _CtxProjFn.apply(ctx_t, self, cdtype, st, *factors)
+        return st
+
+
+class _CtxProjFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ehs, group, cdtype, state, *factors):
+        K = group.K
+        e2 = ehs.reshape(-1, K)
+        if e2.dtype != cdtype:
+            e2 = e2.to(cdtype)
+        if not e2.is_contiguous():
+            e2 = e2.contiguous()
+        M = e2.shape[0]
+        w, _ = group.frozen.get(cdtype, False)
+        tile_part, _ = group.tables(e2.device, M)
+        kv = torch.empty((M, group.total), dtype=cdtype, device=e2.device)
+        t = torch.empty((group.G, M, group.r), dtype=torch.float32, device=e2.device)
+        scale = _same_scale(group.layers)
+        nat.lora_gemm_packed(e2, K, w, None, group.A16, group.B16, tile_part, None, group.G, kv, t, M, K, group.total,
+                             group.r, scale)
+        ctx.save_for_backward(e2, t)
+        ctx.group, ctx.scale = group, scale  # (not `state`: state → kv → this node would be a reference cycle)
+        return kv
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dkv):
+        g = ctx.group
+        e2, t = ctx.saved_tensors
+        M, r = e2.shape[0], g.r
+        d2 = dkv if dkv.is_contiguous() else dkv.contiguous()
+        _, part_table = g.tables(e2.device, M)
+        u = torch.empty((g.G, M, r), dtype=torch.float32, device=e2.device)
+        nat.lora_gemm_packed(d2, g.total, None, None, g.Bt16, None, None, part_table, g.G, None, u, M, 64, 0, r,
+                             ctx.scale, work_cols=g.total)
+        slab = g.sinks[0].slab
+        stride = slab.stride
+        for i, sink in enumerate(g.sinks):
+            slab.defer(nat.grad_problem(d2, g.off[i], g.total, g.N[i], t, i * M * r, r, r, [sink.up_ptr], r, False,
+                                        stride, M, ctx.scale), sink.index, (d2, t))
+            slab.defer(nat.grad_problem(e2, 0, g.K, g.K, u, i * M * r, r, r, [sink.down_ptr], r, True, stride, M,
+                                        ctx.scale), None, (e2, u))
+        return (None, None, None, None) + (None,) * (2 * g.G)
+
+
+class _CtxAttnKVFn(torch.autograd.Function):
+    """Cross-attention core of module `index` of a CtxKVGroup: K / V are column slices of the group's buffer; backward
+    writes dK / dV into the same slices of the group's gradient buffer.  The buffer is handed to autograd exactly once —
+    by the last of the pass's cross-attentions to run backward — so the projections' backward sees every slice filled
+    and nothing is ever added or copied."""
+
+    @staticmethod
+    def forward(ctx, q, kv, group, state, index, heads, scale):
+        q = q if q.is_contiguous() else q.contiguous()
+        off_k, off_v = group.off[2 * index], group.off[2 * index + 1]
+        out = nat.attn_ctx_fwd_kv(q, kv, off_k, off_v, heads, scale)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            ctx.save_for_backward(q, kv)
+            state.consumers += 1
+        ctx.state, ctx.offs, ctx.heads, ctx.scale = state, (off_k, off_v), heads, scale
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        q, kv = ctx.saved_tensors
+        st = ctx.state
+        if st.dkv is None:
+            st.dkv = torch.zeros_like(kv)
+        dq = nat.attn_ctx_bwd_kv(q, kv, st.dkv, ctx.offs[0], ctx.offs[1], dout if dout.is_contiguous() else dout.contiguous(),
+                                 ctx.heads, ctx.scale)
+        st.returned += 1
+        dkv = st.dkv if st.returned == st.consumers else None
+        return dq, dkv, None, None, None, None, None
+
+
+def ctx_cross_attention(group: CtxKVGroup, index: int, q: torch.Tensor, ctx_t: torch.Tensor, heads: int,
+                        scale: Optional[float], cdtype: torch.dtype) -> torch.Tensor:
+    st = group.project(ctx_t, cdtype)
+    if scale is None:
+        scale = (q.shape[-1] // heads) ** -0.5
+    if q.dtype != cdtype:
+        q = q.to(cdtype)
+    return _CtxAttnKVFn.apply(q, st.kv, group, st, index, heads, float(scale))

@@ -111,11 +111,9 @@ class _LoraLinearFn(torch.autograd.Function):
         if need_factors:
             sink = ctx.grad_sink
             if sink is not None:
-                # trainer mode: row-block partials go straight into the model-wide partial slab; the trainer
-                # reduces the whole slab (= the RCCL buffer) in one launch after backward
-                n_blocks = sink.blocks_for(dy2.shape[0])
-                nat.lora_linear_bwd_params_partial(dy2, x2, t, u, sink.ga_part, sink.gb_part, sink.stride, n_blocks,
-                                                   ctx.scale)
+                # trainer mode: nothing is launched here — the two reductions join the slab's batched gradient launch
+                # after backward, their row-block partials land in the model-wide partial slab (= the RCCL buffer's twin)
+                sink.defer_layer(dy2, x2, t, u, ctx.scale)
             else:
                 g_down = torch.zeros_like(a)
                 g_up = torch.zeros_like(b)

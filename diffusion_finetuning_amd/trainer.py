@@ -39,19 +39,40 @@ def lora_layers(model: nn.Module) -> List[LoraInjectedLinear]:
     return [m for m in model.modules() if isinstance(m, LoraInjectedLinear)]
 
 
+class LayerSink:
+    """Where one layer's factor gradients go: device pointers of row block 0 of its `up` (gB) and `down` (gA) slots in the
+    slab's partial-sum buffer.  The backward of a layer does not launch anything for them: it DEFERS two problems to the
+    slab, which launches all problems of a pass together (csrc/lora_grad.hip: lora_grad_batched)."""
+
+    def __init__(self, slab, index: int, up_off: int, down_off: int):
+        self.slab, self.index = slab, index
+        base = slab.partials.data_ptr()
+        self.up_ptr, self.down_ptr = base + 4 * up_off, base + 4 * down_off
+
+    def defer_layer(self, dy2, x2, t, u, scale: float):
+        M, N = dy2.shape
+        K, r = x2.shape[1], t.shape[1]
+        stride = self.slab.stride
+        self.slab.defer(nat.grad_problem(dy2, 0, N, N, t, 0, r, r, [self.up_ptr], r, False, stride, M, scale), self.index,
+                        (dy2, t))
+        self.slab.defer(nat.grad_problem(x2, 0, K, K, u, 0, r, r, [self.down_ptr], r, True, stride, M, scale), None,
+                        (x2, u))
+
+
 class LoraSlab:
     """Re-homes every LoRA factor of `models` into one flat fp32 parameter slab (+ gradient slab).
 
     The nn.Parameter objects stay the same (optimizers, generators and state_dict keep working); only their
-    storage moves.  Each layer gets `_dfa_grad_sink = (grad_down_view, grad_up_view)` so the backward kernel
-    accumulates in place, and `.grad` of each Parameter is a view of the gradient slab."""
-
-    GRAD_BLOCKS = 128
+    storage moves; `.grad` of each Parameter is a view of the gradient slab.  Each layer gets a `_dfa_grad_sink`
+    (LayerSink): its backward defers its two factor-gradient problems here, `flush()` launches everything deferred so
+    far in a few chip-filling launches (the operands — every layer's dY and X — simply stay alive until then: 288 GB of
+    HBM) and folds the row-block partial sums of the layers that ran into the gradient slab, in block order."""
 
     def __init__(self, models: Sequence[nn.Module]):
         self._sinks = []
         self.layers: List[LoraInjectedLinear] = []
         self.model_ranges: List[Tuple[int, int]] = []
+        self.models = list(models)
         for model in models:
             start = sum(l.lora_up.weight.numel() + l.lora_down.weight.numel() for l in self.layers)
             self.layers += lora_layers(model)
@@ -66,89 +87,180 @@ class LoraSlab:
         pad = (-total) % 4  # keep 16-byte granularity for vector loads
         self.numel = total
         self.stride = total + pad
+        self.device = device
         self.params = torch.zeros(total + pad, dtype=torch.float32, device=device)
         self.grads = torch.zeros(total + pad, dtype=torch.float32, device=device)
-        # row-block partial sums of the factor gradients, [GRAD_BLOCKS][slab]: written by the backward kernels
-        # with plain stores, summed in block order by ONE launch per step (deterministic, no atomics)
-        self.partials = torch.zeros((self.GRAD_BLOCKS, total + pad), dtype=torch.float32, device=device)
+        # row-block partial sums of the factor gradients, [blocks][slab]: written by the gradient kernel with plain
+        # stores, summed in block order by the fold (deterministic, no atomics).  Never needs zeroing: a layer's blocks
+        # are fully rewritten whenever it runs, and only layers that ran are folded.
+        self.partials = torch.empty((nat.GRAD_MAX_BLOCKS, total + pad), dtype=torch.float32, device=device)
         self.offsets = []
+        self._pending, self._keep, self._ran = {}, [], {}
+        self._range_tables = {}
+        self.qkv_groups, self.ctx_groups = [], []
+        self.packed = None
         off = 0
-        for layer in self.layers:
-            views = {}
+        for index, layer in enumerate(self.layers):
             for attr in ("lora_up", "lora_down"):  # file order: up then down
                 p = getattr(layer, attr).weight
                 n = p.numel()
                 pv = self.params[off:off + n].view(p.shape)
                 pv.copy_(p.detach().float())
                 p.data = pv
-                gv = self.grads[off:off + n].view(p.shape)
-                p.grad = gv
-                views[attr] = gv
+                p.grad = self.grads[off:off + n].view(p.shape)
                 self.offsets.append((off, n))
                 off += n
-            up_off, down_off = self.offsets[-2][0], self.offsets[-1][0]
-            sink = GradSink(self.partials, up_off, down_off, down_off + self.offsets[-1][1], self.stride, self.GRAD_BLOCKS)
+            sink = LayerSink(self, index, self.offsets[-2][0], self.offsets[-1][0])
             self._sinks.append(sink)
             layer.__dict__["_dfa_grad_sink"] = sink
 
+    # -- grouped projections ---------------------------------------------------------------------
+    def enable_groups(self):
+        """Finds the attention modules under the slab's models and groups their LoRA projections (groups.py): to_q/to_k/
+        to_v of a self-attention into a QKVGroup, to_k/to_v of all cross-attentions over the same context width into a
+        CtxKVGroup.  The groups are used by the attention forward installed with the reference's attention switch
+        (attention.py); a model whose attention runs through its own forward never looks at them."""
+        from .attention import _is_attention_module
+        from .groups import CtxKVGroup, QKVGroup
+
+        index_of = {id(l): i for i, l in enumerate(self.layers)}
+        for model in self.models:
+            cross = {}
+            for name, m in model.named_modules():
+                if not _is_attention_module(m):
+                    continue
+                trio = [m.to_q, m.to_k, m.to_v]
+                if not all(id(l) in index_of for l in trio):
+                    continue
+                # cross-attention: keys/values come from another width, or the block calls it `attn2` (the name diffusers'
+                # BasicTransformerBlock gives its cross-attention in every version the reference supports)
+                is_cross = (m.to_k.linear.in_features != m.to_q.linear.in_features) or name.split(".")[-1] == "attn2"
+                if is_cross:
+                    key = (m.to_k.linear.in_features, m.to_k.lora_down.weight.shape[0])
+                    cross.setdefault(key, []).append(m)
+                elif QKVGroup.eligible(trio):
+                    grp = QKVGroup(trio, [self._sinks[index_of[id(l)]] for l in trio])
+                    m.__dict__["_dfa_qkv"] = grp
+                    self.qkv_groups.append(grp)
+            for mods in cross.values():
+                layers = [l for m in mods for l in (m.to_k, m.to_v)]
+                if len(mods) < 2 or not CtxKVGroup.eligible(layers):
+                    continue
+                grp = CtxKVGroup(mods, layers, [self._sinks[index_of[id(l)]] for l in layers])
+                for i, m in enumerate(mods):
+                    m.__dict__["_dfa_ctx"] = (grp, i)
+                self.ctx_groups.append(grp)
+                model.register_forward_pre_hook(lambda module, args, g=grp: g.new_pass())
+
+    # -- packed compute-dtype factors ------------------------------------------------------------
     def enable_packed(self, dtype: torch.dtype):
-        """Allocates the packed-factor slab (Apack 32·K + Bpack 32·N per layer in the compute dtype, both
-        orientations: lora_hip.h) and the device table for the one-launch re-pack; each layer gets
-        `_dfa_packed = (Apack, Bpack)` views."""
-        rows = []
-        off = 0
-        self._packed_layers = []
+        """Allocates the packed-factor buffer — per layer Apack (32·K) and Bpack (32·N) in the compute dtype, both
+        orientations (lora_hip.h), plus the operands of the grouped projections — and the device table for the one-launch
+        re-pack (lora_pack_items: one row per factor and destination)."""
+        rows, off = [], 0
+        layer_views = []
         for i, layer in enumerate(self.layers):
             r, K = layer.lora_down.weight.shape
             N = layer.lora_up.weight.shape[0]
             if r > 16:
                 continue
             up_off, down_off = self.offsets[2 * i][0], self.offsets[2 * i + 1][0]
-            rows.append([down_off, up_off, K, N, r, off, off + 32 * K, 0])
-            self._packed_layers.append((layer, off, K, N))
+            # {src_off, which, len, r, d16_off, d16_ld, dT_off, rows}
+            rows.append([down_off, 0, K, r, off, K, off + 16 * K, 16])                       # A16 [16,K] | At16 [K,16]
+            rows.append([up_off, 1, N, r, off + 32 * K, N, off + 32 * K + 16 * N, 16])       # Bt16 [16,N] | B16 [N,16]
+            layer_views.append((layer, off, K, N))
             off += 32 * (K + N)
+        index_of = {id(l): i for i, l in enumerate(self.layers)}
+        group_views = []
+        for grp in self.qkv_groups:
+            K, N, r, G = grp.K, grp.N, grp.r, grp.G
+            fa, qb, fb, qa = off, off + 16 * K, off + 16 * K + 16 * G * N, off + 16 * K + 32 * G * N
+            for g, layer in enumerate(grp.layers):
+                i = index_of[id(layer)]
+                up_off, down_off = self.offsets[2 * i][0], self.offsets[2 * i + 1][0]
+                rows.append([down_off, 0, K, r, fa + g * r * K, K, qa + g * r, r])
+                rows.append([up_off, 1, N, r, fb + g * r * G * N + g * N, G * N, qb + g * N * 16 + g * r, r])
+            group_views.append((grp, fa, qb, fb, qa))
+            off += 32 * K + 32 * G * N
+        for grp in self.ctx_groups:
+            K, r, G = grp.K, grp.r, grp.G
+            a16, b16, bt = off, off + 16 * G * K, off + 16 * G * K + 16 * grp.total
+            grp.bt_off = []
+            for g, layer in enumerate(grp.layers):
+                i = index_of[id(layer)]
+                up_off, down_off = self.offsets[2 * i][0], self.offsets[2 * i + 1][0]
+                rows.append([down_off, 0, K, r, a16 + g * 16 * K, K, -1, 16])
+                rows.append([up_off, 1, grp.N[g], r, bt + 16 * grp.off[g], grp.N[g], b16 + 16 * grp.off[g], 16])
+                grp.bt_off.append(16 * grp.off[g])
+            group_views.append((grp, a16, b16, bt))
+            off += 16 * G * K + 32 * grp.total
         if not rows:
             self.packed = None
             return
-        self.packed = torch.zeros(off, dtype=dtype, device=self.params.device)
-        self._pack_table = torch.tensor(rows, dtype=torch.int64, device=self.params.device)
-        self._pack_maxlen = max(max(r_[2], r_[3]) for r_ in rows)
-        for layer, o, K, N in self._packed_layers:
-            layer.__dict__["_dfa_packed"] = (self.packed[o:o + 32 * K], self.packed[o + 32 * K:o + 32 * (K + N)])
+        self.packed = torch.zeros(off, dtype=dtype, device=self.device)  # zeroed ONCE: block-diagonal groups rely on it
+        self._pack_table = torch.tensor(rows, dtype=torch.int64).to(self.device)
+        self._pack_maxlen = max(r_[2] for r_ in rows)
+        pk = self.packed
+        for layer, o, K, N in layer_views:
+            layer.__dict__["_dfa_packed"] = (pk[o:o + 32 * K], pk[o + 32 * K:o + 32 * (K + N)])
+        for view in group_views:
+            grp = view[0]
+            if len(view) == 5:
+                _, fa, qb, fb, qa = view
+                K, GN = grp.K, grp.G * grp.N
+                grp.Fa, grp.Qb, grp.Fb, grp.Qa = pk[fa:fa + 16 * K], pk[qb:qb + 16 * GN], pk[fb:fb + 16 * GN], pk[qa:qa + 16 * K]
+            else:
+                _, a16, b16, bt = view
+                grp.A16 = pk[a16:a16 + 16 * grp.G * grp.K]
+                grp.B16 = pk[b16:b16 + 16 * grp.total]
+                grp.Bt16 = pk[bt:bt + 16 * grp.total]
         self.repack()
 
     def repack(self):
         """Refresh every packed factor from the fp32 master slab (one launch)."""
-        if getattr(self, "packed", None) is not None:
-            nat.lora_pack_factors_batched(self._pack_table, len(self._packed_layers), self._pack_maxlen, self.params,
-                                          self.packed)
+        if self.packed is not None:
+            nat.lora_pack_items(self._pack_table, self._pack_table.shape[0], self._pack_maxlen, self.params, self.packed)
 
+    # -- factor gradients --------------------------------------------------------------------------
     def zero_grad(self):
         self.grads.zero_()
-        for sink in self._sinks:
-            sink.ran = 0
+        self._pending, self._keep, self._ran = {}, [], {}
 
-    def check_all_layers_ran(self):
-        """A layer that did not run backward in this pass still holds an older pass's partials: clear those
-        slices before they are reduced (never the case for a UNet step)."""
-        for sink in self._sinks:
-            if sink.ran == 0:
-                sink.clear(0)
-            elif sink.ran > 1:
-                raise RuntimeError("a LoRA layer ran backward more than once in one pass (shared module?): "
-                                   "the partial-sum layout holds one pass per layer")
-            sink.ran = 0
+    def defer(self, problem, layer_index, keep):
+        """Queue one factor-gradient problem (a `_native.GradProblem`); `keep` = the tensors it reads, held until the
+        launch; `layer_index` marks the layer whose slab range must be folded afterwards (None: covered by a sibling)."""
+        dt = keep[0].dtype
+        self._pending.setdefault(dt, []).append(problem)
+        self._keep.append(keep)
+        if layer_index is not None:
+            nb = nat.grad_row_blocks(problem.M)
+            if self._ran.setdefault(layer_index, nb) != nb:
+                raise RuntimeError("a LoRA layer ran backward twice with different row counts in one pass: the "
+                                   "partial-sum layout holds one pass per layer")
 
-    def reduce_range(self, a: int, b: int):
-        """grads[a:b] += Σ_blocks partials[:, a:b] (block order, deterministic)."""
-        if a % 4:
-            raise RuntimeError("slab range must start on a 16-byte boundary")
-        nat.lora_reduce_partials(self.partials[0, a:], self.stride, self.GRAD_BLOCKS, self.grads[a:], b - a, True)
+    def flush(self):
+        """Launch every deferred problem, then fold the partial sums of the layers that ran into `grads` (+=)."""
+        if not self._pending:
+            return
+        for dt, problems in self._pending.items():
+            nat.lora_grad_batched(problems, dt, self.device)
+        key = tuple(sorted(self._ran.items()))
+        table = self._range_tables.get(key)
+        if table is None:
+            rows = [[self.offsets[2 * i][0], self.offsets[2 * i][1] + self.offsets[2 * i + 1][1], nb, 0] for i, nb in key]
+            table = self._range_tables[key] = (torch.tensor(rows, dtype=torch.int64).to(self.device),
+                                               max(r_[1] for r_ in rows))
+        nat.lora_fold_partials(table[0], len(key), table[1], self.partials, self.stride, self.grads, True)
+        self._pending, self._keep, self._ran = {}, [], {}
 
     def detach_sinks(self):
         for layer in self.layers:
             layer.__dict__.pop("_dfa_grad_sink", None)
             layer.__dict__.pop("_dfa_packed", None)
+        for model in self.models:
+            for m in model.modules():
+                m.__dict__.pop("_dfa_qkv", None)
+                m.__dict__.pop("_dfa_ctx", None)
 
     def range_of(self, module: nn.Module) -> Tuple[int, int]:
         """[start, end) of the slab covering the LoRA layers under `module` (must be contiguous)."""
@@ -158,33 +270,6 @@ class LoraSlab:
             return (0, 0)
         assert idx == list(range(idx[0], idx[-1] + 1)), "layers under the module are not contiguous in the slab"
         return (self.offsets[2 * idx[0]][0], self.offsets[2 * idx[-1] + 1][0] + self.offsets[2 * idx[-1] + 1][1])
-
-
-class GradSink:
-    """Where one layer's factor-gradient kernel stores its row-block partial sums inside the model-wide
-    [GRAD_BLOCKS][slab] buffer.  The number of row blocks follows M (≈128 rows per block, so small layers do not
-    write — and the fold does not read — mostly-empty blocks); blocks a layer stops using are zeroed once."""
-
-    def __init__(self, partials, up_off, down_off, end, stride, max_blocks):
-        self.partials, self.begin, self.end = partials, up_off, end
-        self.ga_part = partials[0, down_off:]
-        self.gb_part = partials[0, up_off:]
-        self.stride, self.max_blocks = stride, max_blocks
-        self.used = 0   # blocks holding data from the last pass
-        self.ran = 0
-
-    def blocks_for(self, M: int) -> int:
-        nb = max(min(4, self.max_blocks), min(self.max_blocks, M // 32))
-        if nb < self.used:
-            self.partials[nb:self.used, self.begin:self.end].zero_()
-        self.used = nb
-        self.ran += 1
-        return nb
-
-    def clear(self, keep: int):
-        if self.used > keep:
-            self.partials[keep:self.used, self.begin:self.end].zero_()
-            self.used = keep
 
 
 class FusedClipAdamW:
@@ -284,16 +369,22 @@ class LoraTrainer:
 
     def __init__(self, unet: nn.Module, text_encoder: Optional[nn.Module] = None, lr=1e-4, lr_text=5e-6,
                  weight_decay=1e-2, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0, loss_scale: Optional[float] = None,
-                 v_prediction=False, process_group=None, always_reduce=False, capture_graph=False):
+                 v_prediction=False, process_group=None, always_reduce=False, capture_graph=False,
+                 group_projections=True):
         """capture_graph: record add_noise → UNet forward → loss → backward of a step once into a hipGraph and
         replay it on later steps with the same shapes (inputs are copied into static buffers).  The partial-sum fold,
         the gradient exchange and the optimizer stay outside the graph, so no collective is ever captured.  Only the
-        plain UNet step is eligible (no text-encoder LoRA, no mask); anything else runs eagerly."""
+        plain UNet step is eligible (no text-encoder LoRA, no mask); anything else runs eagerly.
+        group_projections: run attn1 to_q/to_k/to_v as one launch per block and the attn2 to_k/to_v of all blocks as one
+        launch per pass (groups.py; effective for attention modules switched to the HIP cores with the reference's
+        `set_use_memory_efficient_attention_xformers`)."""
         self.unet, self.text_encoder = unet, text_encoder
         self.capture_graph = bool(capture_graph)
         self._graph = None
         models = [unet] + ([text_encoder] if text_encoder is not None and lora_layers(text_encoder) else [])
         self.slab = LoraSlab(models)
+        if group_projections:
+            self.slab.enable_groups()
         groups = [{"range": self.slab.model_ranges[0], "lr": lr, "weight_decay": weight_decay}]
         if len(models) > 1:
             groups.append({"range": self.slab.model_ranges[1], "lr": lr_text, "weight_decay": weight_decay})
@@ -306,8 +397,7 @@ class LoraTrainer:
         self.sqrt_acp, self.sqrt_1macp = ddpm_tables(device=self.device)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
-        self.exchange = SlabExchange(self.slab.grads, self.slab.numel, process_group, prepare=self.slab.reduce_range,
-                                     always_reduce=always_reduce)
+        self.exchange = SlabExchange(self.slab.grads, self.slab.numel, process_group, always_reduce=always_reduce)
         if self.exchange.active:
             self._broadcast_initial_state()
             self._install_bucket_hook()
@@ -321,17 +411,25 @@ class LoraTrainer:
     def _install_bucket_hook(self):
         """Two buckets in backward-completion order.  Enumeration order is down, up, mid; backward finishes the
         up blocks first, then mid, then the down blocks — so [up|mid] is a contiguous early bucket whose
-        all-reduce overlaps the rest of the backward pass."""
+        all-reduce overlaps the rest of the backward pass (its factor gradients are launched and folded first).
+        Not with a CtxKVGroup: the to_k/to_v gradients of EVERY block then come out of one launch at the end of
+        backward, so no slab range is final before that — the whole slab (5 MB at rank 4) goes in one all-reduce."""
         mid = getattr(self.unet, "mid_block", None)
         ups = getattr(self.unet, "up_blocks", None)
-        if mid is None or ups is None:
+        if mid is None or ups is None or self.slab.ctx_groups:
             return
         a0, a1 = self.slab.range_of(ups)
         b0, b1 = self.slab.range_of(mid)
         if a1 != b0 or a1 <= a0:
             return
         self.exchange.early_range = (a0, b1)
-        mid.register_full_backward_hook(lambda module, gin, gout: self.exchange.launch_early())
+
+        def early(module, gin, gout):
+            if self.exchange._armed:
+                self.slab.flush()
+                self.exchange.launch_early()
+
+        mid.register_full_backward_hook(early)
 
     # -- one step ---------------------------------------------------------------------------------
     def step(self, latents, noise, timesteps, encoder_hidden_states, *, with_prior_preservation=False,
@@ -372,7 +470,7 @@ class LoraTrainer:
         pred_c = pred if pred.is_contiguous() else pred.contiguous()
         loss, dpred = nat.ddpm_mse_fwd_bwd(pred_c, target, m, n_inst, n_prior, prior_loss_weight, self.loss_scale)
         pred_c.backward(dpred)
-        self.slab.check_all_layers_ran()
+        self.slab.flush()  # factor gradients of every layer that ran: batched launch + ordered fold into the slab
         self.exchange.finish()
         self.opt.step(grad_mul=1.0 / (self.world * self.loss_scale))
         self.slab.repack()  # forwards outside step() (sampling, evaluation, saving merged weights) see the new factors
@@ -393,6 +491,7 @@ class LoraTrainer:
         pred_c = pred if pred.is_contiguous() else pred.contiguous()
         loss, dpred = nat.ddpm_mse_fwd_bwd(pred_c, target, None, n_inst, n_prior, st["prior_weight"], self.loss_scale)
         pred_c.backward(dpred)
+        self.slab.flush()
         st["loss"] = loss
 
     def _graph_inputs(self, st, latents, noise, timesteps, ehs, seed):
@@ -449,8 +548,6 @@ class LoraTrainer:
         else:
             self._graph_inputs(st, latents, noise, timesteps, ehs, seed)
         st["graph"].replay()
-        for sink in self.slab._sinks:  # the Python backward fronts do not run on replay: nothing to check
-            sink.ran = 0
         self.exchange.finish()
         self.opt.step(grad_mul=1.0 / (self.world * self.loss_scale))
         self.slab.repack()

@@ -66,6 +66,14 @@ int lora_pack_factors(const float* A, const float* B, void* Apack, void* Bpack, 
 int lora_pack_factors_batched(const int64_t* table, int n_layers, int max_len, const float* params,
                               void* packed, int dtype, void* stream);
 
+/* Packing with explicit destinations, one table row per FACTOR (grouped layers place several layers' factors in one
+ * operand): table[i] = {src_off, which (0: A [r,len], 1: B [len,r]), len, r, d16_off, d16_ld, dT_off, rows} (int64,
+ * device).  Rows j < rows of the [16,len] form go to packed[d16_off + j·d16_ld + c], columns j < rows of the [len,16]
+ * form to packed[dT_off + c·16 + j]; an offset of -1 skips a form; rows = 16 zero-fills unused rank slots, rows = r
+ * leaves them alone (block-diagonal groups write only their own slots of a buffer zeroed once). */
+int lora_pack_items(const int64_t* table, int n_items, int max_len, const float* params, void* packed, int dtype,
+                    void* stream);
+
 /*
  * Forward of LoraInjectedLinear.forward — lora_diffusion/lora.py:49-50
  *     Y = X·Wᵀ + b + s·((X·Aᵀ)·Bᵀ)
@@ -92,6 +100,28 @@ int lora_linear_bwd_input(const void* dY, const void* Wt, const float* A, const 
                           int64_t M, int K, int N, int r, float scale, int dtype, void* stream);
 
 /*
+ * The fused kernel's own contract, for callers that hold PACKED factors only — grouped layers that share an input:
+ *     C[M,Nc] = Am·Bmᵀ + bias + s·P·Qᵀ ,   P[M,r] = Am·Fᵀ                       (P stored unscaled, fp32)
+ * Am [M,Kc] with row stride lda (elements; 0 = Kc), Bm [Nc,Kc], Fp [16,Kc] and Qp [Nc,16] in `dtype` with the
+ * unused rank rows / columns zero.  C == NULL computes P only (backward of a layer whose input needs no gradient).
+ * Uses in the product (lora_diffusion/lora.py:49-50 and its autograd, several LoraInjectedLinear at once):
+ *   - attn1 to_q/to_k/to_v, one launch each way: Bm = [Wq;Wk;Wv] (forward) or its transpose (backward), rank 3r with
+ *     block-diagonal factors — X is read once instead of three times, dX needs no accumulation;
+ *   - the attn2 to_k/to_v of ALL transformer blocks, which multiply the same encoder_hidden_states: forward as one
+ *     launch over the concatenated weights with per-part factors (tile_part[column tile of 64] = part | first<<16,
+ *     Fp = [n_parts·16, Kc], P_out = [n_parts][M][r]); backward (no dX: the text encoder output is frozen) as one
+ *     P-only launch with part_table[g] = {column offset into Am, contraction length, offset into Fp, offset into P_out}.
+ * work_cols: Σ contraction lengths of a part_table launch (profiler accounting only; 0 = Kc).
+ * Returns LORA_E_UNSUPPORTED when the operands are not 16-byte aligned / not a multiple of one K-step (grouping is
+ * then simply not used by the caller).
+ */
+int lora_gemm_packed(const void* Am, int64_t lda, const void* Bm /* nullable with C */, const void* bias /* nullable */,
+                     const void* Fp, const void* Qp, const int* tile_part /* nullable, device */,
+                     const int64_t* part_table /* nullable, device */, int n_parts, void* C /* nullable */,
+                     float* P_out, int64_t M, int Kc, int Nc, int r, float scale, int64_t work_cols, int dtype,
+                     void* stream);
+
+/*
  * Backward w.r.t. the LoRA factors (no grad for W or b: lora.py:179-180 set requires_grad only on
  * lora_up / lora_down; train_lora_dreambooth.py:595 freezes the rest):
  *     gB = s·dYᵀ·T      [N,r]
@@ -109,6 +139,38 @@ int lora_linear_bwd_params(const void* dY, const void* X, const float* T, const 
                            int64_t M, int K, int N, int r, float scale, int dtype, void* stream);
 int lora_reduce_partials(const float* partials, int64_t part_stride, int n_blocks, float* grads,
                          int64_t n, int accumulate, void* stream);
+
+/*
+ * The same two reductions for MANY layers at once — what a training step calls once, after backward, with all
+ * 2×144 problems of an SD1.5 UNet (MI355X-first: 288 GB of HBM keep every layer's dY and X alive until then, and a
+ * few chip-filling launches replace 144 latency-bound ones).  One problem is  G[c,j] = s·Σ_m S[m,c]·P[m,j]:
+ *     S  : streamed operand [M, C] (dtype), row stride s_stride elements — dY for gB, X for gA; may be a strided
+ *          slice of a wider buffer (grouped projections);
+ *     P  : [M, r] fp32, row stride p_stride floats — T for gB, U for gA;
+ *     out: partial output of row block 0; rank columns j are split into groups of `rg`
+ *          (out[j / rg], local column j % rg): one group normally (rg = r); a grouped q/k/v layer hands U as
+ *          [M, 3r] and receives three gA outputs;  out_kn = 1 → out[g] is [rg, C] (gA), 0 → [C, rg] (gB);
+ *     row block b of the problem stores at out[g] + b·part_stride; n_blocks = 0 lets the library choose
+ *          (lora_grad_row_blocks(M), at most LORA_GRAD_MAX_BLOCKS) — the caller folds that many.
+ * `problems` is HOST memory and is consumed during the call (the tables travel as kernel arguments, ≤ 28 problems
+ * per launch; nothing is uploaded, so the call may be recorded into a hipGraph).  lora_fold_partials then sums the
+ * row blocks of a table of slab ranges, each with its own block count:
+ *     grads[off+i] (+)= Σ_{b < blocks} partials[b·part_stride + off + i],  ranges[k] = {off, len, blocks, 0}
+ * (int64, DEVICE memory), max_len = the largest len.  Deterministic like lora_reduce_partials.
+ */
+#define LORA_GRAD_MAX_BLOCKS 64
+typedef struct lora_grad_problem {
+    const void* S;
+    const float* P;
+    float* out[4];
+    int64_t s_stride, p_stride, part_stride, M;
+    int C, r, rg, out_kn, n_blocks;
+    float scale;
+} lora_grad_problem;
+int lora_grad_row_blocks(int64_t M);
+int lora_grad_batched(const lora_grad_problem* problems, int n, int dtype, void* stream);
+int lora_fold_partials(const int64_t* ranges, int n_ranges, int64_t max_len, const float* partials,
+                       int64_t part_stride, float* grads, int accumulate, void* stream);
 
 /*
  * DDPM noise-prediction loss, forward + gradient in one pass —
@@ -236,6 +298,13 @@ int attn_merge_heads_strided(const void* src, void* dst, int B, int N, int H, in
  * Unsupported shapes return LORA_E_BADARG; the caller keeps its generic attention for those.
  */
 int attn_ctx_supported(int B, int Tq, int Tk, int H, int d, int dtype);
+/* _strided forms: K and V (resp. dK and dV) are [B·Tk, ·] column slices of a wider row-major buffer with row stride
+ * ldk (ld_dk) elements — the output (gradient) buffer of a grouped to_k/to_v projection (lora_gemm_packed). */
+int attn_ctx_fwd_strided(const void* Q, const void* K, const void* V, void* O, int64_t ldk, int B, int Tq, int Tk,
+                         int H, int d, float scale, int dtype, void* stream);
+int attn_ctx_bwd_strided(const void* Q, const void* K, const void* V, const void* dO, void* dQ, void* dK, void* dV,
+                         void* workspace, int64_t ldk, int64_t ld_dk, int B, int Tq, int Tk, int H, int d,
+                         float scale, int dtype, void* stream);
 int attn_ctx_fwd(const void* Q, const void* K, const void* V, void* O, int B, int Tq, int Tk, int H, int d,
                  float scale, int dtype, void* stream);
 int64_t attn_ctx_bwd_workspace_bytes(int B, int Tq, int Tk, int H, int d);
@@ -253,6 +322,13 @@ int attn_ctx_bwd(const void* Q, const void* K, const void* V, const void* dO, vo
  *                                   dQ), every output element written by one workgroup: deterministic, no atomics.
  */
 int attn_flash_supported(int B, int Tq, int Tk, int H, int d, int dtype);
+/* _strided forms: Q, K, V share the row stride ldq and dQ, dK, dV the row stride ld_dq (elements): the three column
+ * slices of a grouped to_q/to_k/to_v projection's output / gradient buffer.  O, dO, LSE stay dense. */
+int attn_flash_fwd_strided(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t ldq, int B,
+                           int Tq, int Tk, int H, int d, float scale, int dtype, void* stream);
+int attn_flash_bwd_strided(const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                           const float* LSE, void* dQ, void* dK, void* dV, void* workspace, int64_t ldq,
+                           int64_t ld_dq, int B, int Tq, int Tk, int H, int d, float scale, int dtype, void* stream);
 int attn_flash_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int Tq, int Tk, int H,
                    int d, float scale, int dtype, void* stream);
 int64_t attn_flash_bwd_workspace_bytes(int B, int Tq, int H);

@@ -58,6 +58,36 @@ def relerr():
     return rel_err
 
 
+def err_stats(a, b):
+    """(whole-tensor relative L2, largest element error / rms(ref), worst ROW's relative L2).  The whole-tensor ratio
+    alone lets one badly wrong edge-tile row or a handful of wrong elements through at 1e-3; the other two do not."""
+    a, b = a.double().cpu(), b.double().cpu()
+    d = a - b
+    rms = b.pow(2).mean().sqrt().item() + 1e-30
+    rel = (d.norm() / (b.norm() + 1e-30)).item()
+    max_abs = d.abs().max().item() / rms if d.numel() else 0.0
+    if b.dim() >= 2 and b.shape[-1] > 1:
+        d2, b2 = d.reshape(-1, d.shape[-1]), b.reshape(-1, b.shape[-1])
+        floor = 0.05 * rms * b2.shape[-1] ** 0.5  # rows that are ~zero are judged against the typical row
+        worst = (d2.norm(dim=-1) / (b2.norm(dim=-1) + floor)).max().item() if d2.numel() else 0.0
+    else:
+        worst = rel
+    return rel, max_abs, worst
+
+
+def assert_close(got, ref, tol, what=""):
+    """rel L2 < tol, every element within 8·tol of the reference's rms, every row within 4·tol relative."""
+    rel, max_abs, worst = err_stats(got, ref)
+    assert rel < tol, (what, "rel", rel)
+    assert max_abs < 8 * tol, (what, "max_abs/rms", max_abs)
+    assert worst < 4 * tol, (what, "worst_row", worst)
+
+
+@pytest.fixture(scope="session")
+def close():
+    return assert_close
+
+
 def build_tiny_unet(seed=0):
     from harness.unet import UNet2DConditionModel, tiny_config
 

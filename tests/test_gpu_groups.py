@@ -1,0 +1,372 @@
+"""Round-2 kernels through the C-ABI: the batched factor-gradient launch, the table-driven fold, grouped LoRA
+projections (q/k/v of a self-attention, K/V of all cross-attentions), the strided attention cores that consume them,
+and the full-size BASELINE configurations that were only covered in miniature before.  Checked against float64 math,
+against the ungrouped kernels, and against the CPU oracle."""
+import itertools
+
+import pytest
+import torch
+
+import diffusion_finetuning_amd as dfa
+from diffusion_finetuning_amd import _native as nat
+from diffusion_finetuning_amd import trainer as tr
+from diffusion_finetuning_amd.attention import set_use_hip_geglu, set_use_memory_efficient_attention_xformers
+from oracle import lora_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = {torch.float32: 2e-5, torch.float16: 1e-3, torch.bfloat16: 1e-2}
+
+
+def _ref_grad(S, P, scale):
+    return scale * (S.double().t() @ P.double())  # [C, r]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_batched_factor_gradients_vs_float64(close, dtype):
+    """lora_grad_batched: many problems in one call (more than one 28-problem launch), strided S and P slices, all
+    three rank classes, a rank-grouped gA (one problem, three outputs), ragged row counts, library-chosen row blocks —
+    then lora_fold_partials with per-range block counts.  Untouched slab cells must stay untouched."""
+    g = torch.Generator().manual_seed(5)
+    specs = []  # (M, C, r, rg, out_kn, strided)
+    for i in range(40):
+        M = [4096, 308, 1024, 77, 2500][i % 5]
+        C = [320, 640, 1280, 64, 2560][(i // 2) % 5]
+        r = [4, 1, 8, 16, 12][i % 5]
+        rg = 4 if r == 12 else r
+        specs.append((M, C, r, rg, i % 2 == 0 or r == 12, i % 3 == 0))
+    # slab layout: each problem owns (r/rg) ranges of rg·C floats
+    offs, off = [], 0
+    for (M, C, r, rg, kn, st) in specs:
+        groups = r // rg
+        offs.append([off + k * rg * C for k in range(groups)])
+        off += r * C
+    stride = (off + 3) // 4 * 4
+    partials = torch.full((nat.GRAD_MAX_BLOCKS, stride), float("nan"), device=DEV)
+    grads = torch.ones(stride, device=DEV)
+    problems, refs, keep, ranges = [], [], [], []
+    for (M, C, r, rg, kn, st), o in zip(specs, offs):
+        wide = C + 128 if st else C
+        Sfull = torch.randn(M, wide, generator=g).to(dtype).to(DEV)
+        Pfull = torch.randn(M, r + (8 if st else 0), generator=g).to(DEV)
+        s_off, p_off = (64, 8) if st else (0, 0)
+        S, P = Sfull[:, s_off:s_off + C], Pfull[:, p_off:p_off + r]
+        scale = 0.7
+        outs = [partials.data_ptr() + 4 * x for x in o]
+        problems.append(nat.grad_problem(Sfull, s_off, wide, C, Pfull, p_off, Pfull.shape[1], r, outs, rg, kn, stride, M,
+                                         scale))
+        keep.append((Sfull, Pfull))
+        refs.append(_ref_grad(S, P, scale))
+        nb = nat.grad_row_blocks(M)
+        for x in o:
+            ranges.append([x, rg * C, nb, 0])
+    nat.lora_grad_batched(problems, dtype, torch.device(DEV, 0))
+    table = torch.tensor(ranges, dtype=torch.int64).to(DEV)
+    nat.lora_fold_partials(table, len(ranges), max(r_[1] for r_ in ranges), partials, stride, grads, True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(grads).all()
+    tol = TOL[dtype]
+    for (M, C, r, rg, kn, st), o, ref in zip(specs, offs, refs):
+        for k, x in enumerate(o):
+            got = grads[x:x + rg * C] - 1.0  # accumulate=True onto ones
+            want = ref[:, k * rg:(k + 1) * rg]  # [C, rg]
+            got = got.view(rg, C).t() if kn else got.view(C, rg)
+            close(got, want, max(tol, 2e-5), (M, C, r, rg, kn, st, k))
+    # determinism
+    grads2 = torch.ones(stride, device=DEV)
+    nat.lora_grad_batched(problems, dtype, torch.device(DEV, 0))
+    nat.lora_fold_partials(table, len(ranges), max(r_[1] for r_ in ranges), partials, stride, grads2, True)
+    assert torch.equal(grads, grads2)
+
+
+def test_pack_items_layouts():
+    """lora_pack_items: per-layer [A16|At16], [Bt16|B16] and the block-diagonal q/k/v layout (rows = r, destinations
+    offset, buffer zeroed once)."""
+    g = torch.Generator().manual_seed(2)
+    K, N, r, G = 64, 128, 4, 3
+    A = [torch.randn(r, K, generator=g) for _ in range(G)]
+    B = [torch.randn(N, r, generator=g) for _ in range(G)]
+    params = torch.cat([t.reshape(-1) for pair in zip(B, A) for t in pair]).to(DEV)  # [up0, down0, up1, ...]
+    up_off = [i * (N * r + r * K) for i in range(G)]
+    down_off = [o + N * r for o in up_off]
+    fa, qb, fb, qa = 0, 16 * K, 16 * K + 16 * G * N, 16 * K + 32 * G * N
+    single = qa + 16 * K
+    rows = []
+    for i in range(G):
+        rows.append([down_off[i], 0, K, r, fa + i * r * K, K, qa + i * r, r])
+        rows.append([up_off[i], 1, N, r, fb + i * r * G * N + i * N, G * N, qb + i * N * 16 + i * r, r])
+    rows.append([down_off[1], 0, K, r, single, K, single + 16 * K, 16])
+    rows.append([up_off[1], 1, N, r, single + 32 * K, N, single + 32 * K + 16 * N, 16])
+    packed = torch.zeros(single + 32 * (K + N), dtype=torch.float16, device=DEV)
+    packed[single:] = 7.0  # rows = 16 must overwrite everything, including the padding slots
+    nat.lora_pack_items(torch.tensor(rows, dtype=torch.int64).to(DEV), len(rows), max(K, N), params, packed)
+    pk = packed.float().cpu()
+    Fa, Qb = pk[fa:fa + 16 * K].view(16, K), pk[qb:qb + 16 * G * N].view(G * N, 16)
+    Fb, Qa = pk[fb:fb + 16 * G * N].view(16, G * N), pk[qa:qa + 16 * K].view(K, 16)
+    wFa, wQb, wFb, wQa = torch.zeros(16, K), torch.zeros(G * N, 16), torch.zeros(16, G * N), torch.zeros(K, 16)
+    for i in range(G):
+        a, b = A[i].half().float(), B[i].half().float()
+        wFa[i * r:(i + 1) * r] = a
+        wQa[:, i * r:(i + 1) * r] = a.t()
+        wQb[i * N:(i + 1) * N, i * r:(i + 1) * r] = b
+        wFb[i * r:(i + 1) * r, i * N:(i + 1) * N] = b.t()
+    assert torch.equal(Fa, wFa) and torch.equal(Qb, wQb) and torch.equal(Fb, wFb) and torch.equal(Qa, wQa)
+    a, b = A[1].half().float(), B[1].half().float()
+    s = pk[single:]
+    assert torch.equal(s[:16 * K].view(16, K)[:r], a) and float(s[:16 * K].view(16, K)[r:].abs().max()) == 0.0
+    assert torch.equal(s[16 * K:32 * K].view(K, 16)[:, :r], a.t())
+    assert torch.equal(s[32 * K:32 * K + 16 * N].view(16, N)[:r], b.t())
+    assert torch.equal(s[32 * K + 16 * N:].view(N, 16)[:, :r], b) and float(s[32 * K + 16 * N:].view(N, 16)[:, r:].abs().max()) == 0.0
+
+
+def _tiny64(seed=3):
+    from harness.unet import UNet2DConditionModel, tiny_config
+
+    torch.manual_seed(seed)
+    unet = UNet2DConditionModel(tiny_config(64, 64, 2))  # widths 64/128, context 64: every projection is groupable
+    unet.requires_grad_(False)
+    return unet
+
+
+def _warm(params, seed=11, std=0.02):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for i, p in enumerate(params):
+            if i % 2 == 0:
+                p.copy_((torch.randn(p.shape, generator=g) * std).to(p.device))
+
+
+def _train(grouped, hook, steps=4, dtype=torch.float32, graph=False, prior=False, batch=2):
+    unet = _tiny64().to(DEV).to(dtype)
+    params, _ = dfa.inject_trainable_lora(unet, r=4)
+    _warm(list(itertools.chain(*params)))
+    if hook:
+        set_use_memory_efficient_attention_xformers(unet, True)
+    trainer = tr.LoraTrainer(unet, lr=1e-3, group_projections=grouped, capture_graph=graph)
+    losses = []
+    for step in range(steps):
+        lat, noise, ts, ctx = orc.synthetic_batch(step, batch, 8, 6, 64)
+        losses.append(trainer.step(lat.to(DEV), noise.to(DEV), ts.to(DEV), ctx.to(DEV), with_prior_preservation=prior))
+    return trainer, tr.flat_lora_state(unet).cpu(), torch.stack(losses).cpu()
+
+
+def test_grouped_projections_follow_the_ungrouped_trajectory(relerr):
+    """Same model, same steps: grouped q/k/v + grouped context K/V (one launch each) against one launch per layer.
+    f16 (the attention cores are 16-bit kernels); the two runs differ only in kernel tiling / summation order."""
+    t_g, got, lg = _train(True, True, dtype=torch.float16)
+    n_blocks = sum(1 for m in t_g.unet.modules() if type(m).__name__ == "BasicTransformerBlock")
+    assert n_blocks == 4
+    assert len(t_g.slab.qkv_groups) == n_blocks and len(t_g.slab.ctx_groups) == 1
+    assert t_g.slab.ctx_groups[0].G == 2 * n_blocks
+    t_u, want, lu = _train(False, True, dtype=torch.float16)
+    assert not t_u.slab.qkv_groups and not t_u.slab.ctx_groups
+    assert relerr(lg, lu) < 2e-3, relerr(lg, lu)
+    assert relerr(got, want) < 2e-3, relerr(got, want)
+    # the groups really ran: their passes left state behind
+    assert t_g.slab.ctx_groups[0]._pass is not None and t_g.slab.ctx_groups[0]._pass.consumers == n_blocks
+    # and against the fp32 CPU oracle (stock attention arithmetic)
+    ref = _tiny64()
+    ref_params, _ = orc.inject(ref, r=4)
+    _warm(ref_params)
+    ref_losses = orc.train_steps(ref, ref_params, 4, 2, 8, 6, 64, lr=1e-3)
+    assert relerr(lg, torch.tensor(ref_losses)) < 5e-3
+    assert relerr(got, orc.flat_params(ref_params)) < 5e-3
+
+
+def test_grouped_projections_with_prior_preservation_and_hipgraph(relerr):
+    _, want, lw = _train(True, True, dtype=torch.float16, prior=True)
+    tg, got, lg = _train(True, True, dtype=torch.float16, prior=True, graph=True)
+    assert tg._graph is not None
+    assert relerr(got, want) < 2e-5 and relerr(lg, lw) < 2e-5, (relerr(got, want), relerr(lg, lw))
+
+
+def test_groups_stay_out_of_the_way_without_the_attention_hook(relerr):
+    """A trainer with groups enabled on a model whose attention runs through its own forward: groups are built but
+    never used, and the result equals the ungrouped trainer bit for bit."""
+    _, a, la = _train(True, False)
+    _, b, lb = _train(False, False)
+    assert torch.equal(a, b) and torch.equal(la, lb)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_strided_attention_cores_equal_the_dense_ones(dtype):
+    """attn_flash_*_strided on q|k|v column slices of one buffer and attn_ctx_*_strided on K/V slices of a wide buffer
+    must equal the dense entry points on contiguous copies, bit for bit (same kernels, different row strides)."""
+    from diffusion_finetuning_amd.sandwich import ctx_attention, flash_attention
+
+    g = torch.Generator().manual_seed(9)
+    for (B, T, H, d) in ((2, 256, 2, 40), (1, 1000, 4, 80), (1, 200, 8, 160), (2, 4096, 8, 40)):
+        qkv = torch.randn(B, T, 3 * H * d, generator=g).to(dtype).to(DEV)
+        go = torch.randn(B, T, H * d, generator=g).to(dtype).to(DEV)
+        o, lse = nat.attn_flash_fwd_qkv(qkv, H, d ** -0.5)
+        dqkv = nat.attn_flash_bwd_qkv(qkv, o, go, lse, H, d ** -0.5)
+        q, k, v = (t.contiguous().requires_grad_(True) for t in qkv.split(H * d, dim=-1))
+        want = flash_attention(q, k, v, H)
+        want.backward(go)
+        assert torch.equal(o, want)
+        assert torch.equal(dqkv, torch.cat([q.grad, k.grad, v.grad], dim=-1))
+    for (B, Tq, Tk, H, d, wide, ok, ov) in ((2, 300, 77, 8, 40, 1024, 64, 512), (1, 100, 77, 8, 160, 2560 + 64, 0, 1280 + 64)):
+        kv = torch.randn(B * Tk, wide, generator=g).to(dtype).to(DEV)
+        q = torch.randn(B, Tq, H * d, generator=g).to(dtype).to(DEV)
+        go = torch.randn(B, Tq, H * d, generator=g).to(dtype).to(DEV)
+        o = nat.attn_ctx_fwd_kv(q, kv, ok, ov, H, d ** -0.5)
+        dkv = torch.zeros_like(kv)
+        dq = nat.attn_ctx_bwd_kv(q, kv, dkv, ok, ov, go, H, d ** -0.5)
+        qq = q.clone().requires_grad_(True)
+        kk = kv[:, ok:ok + H * d].reshape(B, Tk, H * d).contiguous().requires_grad_(True)
+        vv = kv[:, ov:ov + H * d].reshape(B, Tk, H * d).contiguous().requires_grad_(True)
+        want = ctx_attention(qq, kk, vv, H)
+        want.backward(go)
+        assert torch.equal(o, want) and torch.equal(dq, qq.grad)
+        assert torch.equal(dkv[:, ok:ok + H * d].reshape(B, Tk, H * d), kk.grad)
+        assert torch.equal(dkv[:, ov:ov + H * d].reshape(B, Tk, H * d), vv.grad)
+        mask = torch.ones(wide, dtype=torch.bool)
+        mask[ok:ok + H * d] = mask[ov:ov + H * d] = False
+        assert float(dkv[:, mask.to(DEV)].abs().max()) == 0.0  # nothing outside the two slices is written
+
+
+def test_grouped_context_projection_equals_per_layer_launches(close):
+    """lora_gemm_packed with tile_part (forward of 6 K/V projections of different widths in ONE launch) and with
+    part_table (their U = dY·B in one P-only launch) against lora_linear_fwd / lora_linear_bwd_input per layer."""
+    g = torch.Generator().manual_seed(4)
+    dtype, K, r, M = torch.float16, 768, 4, 308
+    widths = [320, 320, 640, 640, 1280, 1280]
+    total = sum(widths)
+    x = torch.randn(M, K, generator=g).to(dtype).to(DEV)
+    Ws = [((torch.rand(n, K, generator=g) * 2 - 1) / K ** 0.5).to(dtype).to(DEV) for n in widths]
+    As = [(torch.randn(r, K, generator=g) / r).to(DEV) for _ in widths]
+    Bs = [(torch.randn(n, r, generator=g) * 0.05).to(DEV) for n in widths]
+    dY = torch.randn(M, total, generator=g).to(dtype).to(DEV)
+    params = torch.cat([t.reshape(-1) for pair in zip(Bs, As) for t in pair])
+    offs, o = [], 0
+    for n in widths:
+        offs.append(o)
+        o += n
+    G = len(widths)
+    a16, b16, bt = 0, 16 * G * K, 16 * G * K + 16 * total
+    rows, po = [], 0
+    for i, n in enumerate(widths):
+        up_off, down_off = po, po + n * r
+        po += n * r + r * K
+        rows.append([down_off, 0, K, r, a16 + i * 16 * K, K, -1, 16])
+        rows.append([up_off, 1, n, r, bt + 16 * offs[i], n, b16 + 16 * offs[i], 16])
+    packed = torch.zeros(bt + 16 * total, dtype=dtype, device=DEV)
+    nat.lora_pack_items(torch.tensor(rows, dtype=torch.int64).to(DEV), len(rows), max(K, max(widths)), params, packed)
+    tp = []
+    for i, n in enumerate(widths):
+        tp += [i | (1 << 16)] + [i] * (n // 64 - 1)
+    tile_part = torch.tensor(tp, dtype=torch.int32).to(DEV)
+    Y = torch.empty(M, total, dtype=dtype, device=DEV)
+    T = torch.full((G, M, r), float("nan"), device=DEV)
+    nat.lora_gemm_packed(x, K, torch.cat(Ws), None, packed[a16:b16], packed[b16:bt], tile_part, None, G, Y, T, M, K, total, r,
+                         0.7)
+    part_table = torch.tensor([[offs[i], widths[i], 16 * offs[i], i * M * r] for i in range(G)], dtype=torch.int64).to(DEV)
+    U = torch.full((G, M, r), float("nan"), device=DEV)
+    nat.lora_gemm_packed(dY, total, None, None, packed[bt:], None, None, part_table, G, None, U, M, 64, 0, r, 0.7,
+                         work_cols=total)
+    for i, n in enumerate(widths):
+        y_i, t_i = nat.lora_linear_fwd(x, Ws[i], None, As[i], Bs[i], 0.7)
+        _, u_i = nat.lora_linear_bwd_input(dY[:, offs[i]:offs[i] + n].contiguous(), None, As[i], Bs[i], 0.7, False)
+        close(Y[:, offs[i]:offs[i] + n], y_i, 1e-3, ("y", i))
+        close(T[i], t_i, 1e-5, ("t", i))
+        close(U[i], u_i, 1e-5, ("u", i))
+        y_ref = orc.lora_linear_forward(x.double().cpu(), Ws[i].double().cpu(), None, As[i].half().double().cpu(),
+                                        Bs[i].half().double().cpu(), 0.7)
+        close(Y[:, offs[i]:offs[i] + n], y_ref, 1e-3, ("y vs f64", i))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16])
+def test_flash_attention_sd21_768_self_attention_shape(relerr, dtype):
+    """cfg-5 (SD2.1-768): 96×96 latents → 9216 tokens, 5 heads of 64.  Row-permutation property on the full problem, a
+    float64 check on a 512-query slice, and large logits (scores scaled 12×) so the online-softmax rescale really runs."""
+    from diffusion_finetuning_amd.sandwich import flash_attention
+
+    g = torch.Generator().manual_seed(77)
+    B, T, H, d = 1, 9216, 5, 64
+    q = (torch.randn(B, T, H * d, generator=g) * 3.5).to(dtype)
+    k = (torch.randn(B, T, H * d, generator=g) * 3.5).to(dtype)  # q·k/√d has std ≈ 12
+    v = torch.randn(B, T, H * d, generator=g).to(dtype)
+    go = torch.randn(B, T, H * d, generator=g).to(dtype)
+    qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    out = flash_attention(qd, kd, vd, H)
+    out.backward(go.to(DEV))
+    assert torch.isfinite(out).all() and torch.isfinite(qd.grad).all() and torch.isfinite(kd.grad).all()
+    # float64 reference for 512 query rows (all keys): o and dq of those rows
+    rows = torch.arange(1000, 1512)
+    qr = q[:, rows].double().requires_grad_(True)
+    kr, vr = k.double().requires_grad_(True), v.double().requires_grad_(True)
+    s = torch.einsum("bqhd,bkhd->bhqk", qr.view(B, -1, H, d), kr.view(B, T, H, d)) * d ** -0.5
+    o_ref = torch.einsum("bhqk,bkhd->bqhd", s.softmax(-1), vr.view(B, T, H, d)).reshape(B, -1, H * d)
+    o_ref.backward(go[:, rows].double())
+    assert relerr(out[:, rows], o_ref) < 2e-3 and relerr(qd.grad[:, rows], qr.grad) < 4e-3
+    # query-row permutation permutes the output rows (and leaves dK/dV unchanged up to summation order)
+    perm = torch.randperm(T, generator=g)
+    q2 = q[:, perm].to(DEV).requires_grad_(True)
+    k2, v2 = kd.detach().clone().requires_grad_(True), vd.detach().clone().requires_grad_(True)
+    out2 = flash_attention(q2, k2, v2, H)
+    out2.backward(go[:, perm].to(DEV))
+    assert torch.equal(out2, out[:, perm.to(DEV)])
+    assert relerr(k2.grad, kd.grad) < 2e-3 and relerr(v2.grad, vd.grad) < 2e-3
+
+
+def _sd15(device, dtype, seed=0):
+    from harness.unet import UNet2DConditionModel, sd15_config
+
+    torch.manual_seed(seed)
+    with torch.device(device):
+        m = UNet2DConditionModel(sd15_config())
+    m.requires_grad_(False)
+    return m.to(dtype)
+
+
+@pytest.mark.parametrize("prior", [False, True])
+def test_full_size_fp16_step_vs_fp32_cpu_oracle(relerr, prior):
+    """BASELINE config 2 (batch 4, 64×64 latents, f16, grouped projections + HIP attention cores, exactly what bench.py
+    times) and config 4's per-GPU step (prior preservation: 4 instance + 4 class rows → M = 32768): ONE full-size step
+    each against the fp32 CPU oracle on the same weights and inputs — loss and the LoRA UPDATE (tolerance of the
+    existing cfg-1 check on the update; f16 compute)."""
+    import bench
+
+    torch.set_num_threads(bench.usable_cpus())
+    batch = 8 if prior else 4
+    ref = _sd15("cpu", torch.float32)
+    ref_params, _ = orc.inject(ref, r=4)
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for i, p in enumerate(ref_params):
+            if i % 2 == 0:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.01)
+    init_state = orc.flat_params(ref_params).clone()
+    state = {k: v.clone() for k, v in ref.state_dict().items() if "lora_" not in k}
+    ref_losses = orc.train_steps(ref, ref_params, 1, batch, 64, 77, 768, lr=1e-4, with_prior=prior)
+    ref_grad = torch.cat([p.grad.reshape(-1) for p in ref_params])  # clipped in place: a global factor, direction kept
+    want = orc.flat_params(ref_params)
+    del ref
+
+    unet = _sd15("cpu", torch.float32)
+    unet.load_state_dict({k.replace(".linear.", "."): v for k, v in state.items()})
+    unet = unet.half().to(DEV)
+    params, _ = dfa.inject_trainable_lora(unet, r=4)
+    plist = list(itertools.chain(*params))
+    with torch.no_grad():
+        for p, rp in zip(plist, torch.split(init_state, [q.numel() for q in plist])):
+            p.copy_(rp.view(p.shape).to(DEV))
+    set_use_memory_efficient_attention_xformers(unet, True)
+    set_use_hip_geglu(unet, True)
+    trainer = tr.LoraTrainer(unet, lr=1e-4)
+    assert len(trainer.slab.qkv_groups) == 16 and trainer.slab.ctx_groups[0].G == 32
+    lat, noise, ts, ctx = orc.synthetic_batch(0, batch, 64, 77, 768)
+    loss = trainer.step(lat.to(DEV), noise.to(DEV), ts.to(DEV), ctx.to(DEV), with_prior_preservation=prior).item()
+    assert not trainer.opt.overflowed()
+    got = tr.flat_lora_state(unet).cpu()
+    assert abs(loss - ref_losses[0]) / abs(ref_losses[0]) < 2e-3, (loss, ref_losses[0])
+    # the gradient slab (what the all-reduce carries), direction against the oracle's: whole slab and worst layer
+    grad = trainer.slab.grads[: trainer.slab.numel].cpu()
+    gn, rn = grad / grad.norm(), ref_grad / ref_grad.norm()
+    assert relerr(gn, rn) < 1e-2, relerr(gn, rn)
+    worst = max(relerr(gn[o:o + n], rn[o:o + n]) for o, n in trainer.slab.offsets)
+    assert worst < 5e-2, worst
+    # one AdamW step moves every element by ≈ ±lr·sign(g): the signs must agree except at gradient zero-crossings
+    agree = (((got - init_state) * (want - init_state)) > 0).float().mean().item()
+    assert agree > 0.99, agree
+    assert relerr(got, want) < 1e-3

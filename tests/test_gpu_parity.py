@@ -28,7 +28,7 @@ def _bf16_safe(t, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
-def test_operator_against_reference_golden(golden_operator, relerr, dtype):
+def test_operator_against_reference_golden(golden_operator, relerr, close, dtype):
     t, meta = golden_operator
     for c in [k for k in meta if k.startswith("c")]:
         cfg = json.loads(meta[c])
@@ -52,10 +52,10 @@ def test_operator_against_reference_golden(golden_operator, relerr, dtype):
         ga, gb = torch.zeros_like(down), torch.zeros_like(up)
         nat.lora_linear_bwd_params(dy, x, T, U, ga, gb, s)
         tol = TOL[dtype]
-        assert relerr(y, y_ref) < tol, (c, "y")
-        assert relerr(dx, dx_ref) < tol, (c, "dx")
-        assert relerr(ga, gd_ref) < tol, (c, "g_down")
-        assert relerr(gb, gu_ref) < tol, (c, "g_up")
+        close(y, y_ref, tol, (c, "y"))
+        close(dx, dx_ref, tol, (c, "dx"))
+        close(ga, gd_ref, tol, (c, "g_down"))
+        close(gb, gu_ref, tol, (c, "g_up"))
         # no-input-grad variant (attn2 to_k/to_v): same U, no dX
         dx_none, U2 = nat.lora_linear_bwd_input(dy, None, down, up, s, False)
         assert dx_none is None and relerr(U2, U) < 1e-6
@@ -65,12 +65,16 @@ SD_SHAPES = [  # (M, K, N, bias): the distinct LoRA GEMMs of SD1.5 at 512² / B=
     (2048, 320, 320, True), (1024, 320, 2560, True), (308, 768, 320, False), (1024, 640, 640, False),
     (512, 640, 5120, True), (308, 768, 640, False), (1024, 1280, 1280, True), (256, 1280, 10240, True),
     (308, 768, 1280, False), (77, 768, 320, False), (144, 1024, 1280, False),
+    # cfg-3: CLIP-L attention projections at B=4 (77·4 rows); cfg-5: SD2.1-768 (96² latents, 1024-wide context);
+    # long contractions on small grids (the deep-ring path); ragged row counts
+    (308, 768, 768, True), (9216, 320, 320, False), (2304, 640, 640, True), (2304, 1024, 640, False),
+    (576, 1280, 1280, True), (256, 1280, 1280, False), (1024, 10240, 1280, False), (333, 320, 960, False),
 ]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("r", [1, 4, 8, 16])
-def test_operator_against_oracle_sd_shapes(relerr, dtype, r):
+def test_operator_against_oracle_sd_shapes(relerr, close, dtype, r):
     g = torch.Generator().manual_seed(100 + r)
     for (M, K, N, bias) in SD_SHAPES[:: (2 if r in (1, 8) else 1)]:
         x = torch.randn(M, K, generator=g).to(dtype)
@@ -89,7 +93,7 @@ def test_operator_against_oracle_sd_shapes(relerr, dtype, r):
         nat.lora_linear_bwd_params(dyd, xd, T, U, ga, gb, s)
         tol = TOL[dtype]
         for name, got, ref in (("y", y, y_ref), ("dx", dx, dx_ref), ("ga", ga, gd_ref), ("gb", gb, gu_ref)):
-            assert relerr(got, ref) < tol, (M, K, N, r, name)
+            close(got, ref, tol, (M, K, N, r, name))
 
 
 def test_edge_cases_empty_and_single_row(relerr):
@@ -420,7 +424,7 @@ def test_rccl_bucketed_exchange_single_rank(golden_trajectory, tiny_unet_factory
         unet = tiny_unet_factory(seed=cfg["unet_seed"]).to(DEV)
         params, _ = dfa.inject_trainable_lora(unet, r=4)
         _warm(list(itertools.chain(*params)), cfg["warm_seed"], cfg["warm_std"])
-        trainer = tr.LoraTrainer(unet, lr=cfg["lr"], always_reduce=True)
+        trainer = tr.LoraTrainer(unet, lr=cfg["lr"], always_reduce=True, group_projections=False)
         assert trainer.exchange.active and trainer.exchange.early_range is not None
         a, b = trainer.exchange.early_range
         assert 0 < a < b == trainer.slab.numel  # [down | up | mid]: the early bucket is the tail

@@ -1,33 +1,32 @@
-"""Dev tool: per-shape device time of the hot-path kernels (dispatch-attached events), optional forced tile.
-usage: [LORA_FORCE_TILE=0|1|2] python tools/gemm_bench.py [--grad] [--ref]"""
+"""Dev tool: per-shape device time of the hot-path kernels (dispatch-attached events).
+usage: [LORA_FORCE_TILE=0|2] [LORA_FORCE_STAGES=2|3|4|6] python tools/gemm_bench.py [--grouped] [--grads] [--ref]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from diffusion_finetuning_amd import _native as nat
 dev = "cuda"
-SHAPES = [(16384,320,320),(16384,320,2560),(16384,1280,320),(4096,640,640),(4096,640,5120),(4096,2560,640),(1024,1280,1280),(1024,1280,10240),(1024,5120,1280),(256,1280,1280),(308,768,320),(308,768,1280)]
+SHAPES = [(16384,320,320),(16384,320,2560),(16384,1280,320),(4096,640,640),(4096,640,5120),(4096,2560,640),(1024,1280,1280),(1024,1280,10240),(1024,5120,1280),(256,1280,1280),(256,1280,10240),(308,768,320),(308,768,1280)]
 def run(fn, iters=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()
-    nat.prof_enable(iters + 4)
+    nat.prof_enable(16 * iters + 64)
     for _ in range(iters): fn()
     torch.cuda.synchronize()
     res = nat.prof_collect(); nat.prof_enable(0)
     tot = sum(v["ms"] for v in res.values()); n = sum(v["launches"] for v in res.values())
-    return 1e3 * tot / n, list(res.keys())
-def main():
+    return 1e3 * tot / iters, n / iters, list(res.keys())
+def per_shape():
     dtype = torch.float16
-    print("tile override:", os.environ.get("LORA_FORCE_TILE"))
+    print("tile", os.environ.get("LORA_FORCE_TILE"), "stages", os.environ.get("LORA_FORCE_STAGES"))
     for (M,K,N) in SHAPES:
         x = torch.randn(M,K,device=dev).to(dtype); w = (torch.randn(N,K,device=dev)/K**0.5).to(dtype); wt = w.t().contiguous()
         a = torch.randn(4,K,device=dev)/4; b = torch.randn(N,4,device=dev)*0.05; dy = torch.randn(M,N,device=dev).to(dtype)
         y, t = nat.lora_linear_fwd(x,w,None,a,b,1.0); dx,u = nat.lora_linear_bwd_input(dy,wt,a,b,1.0,True)
         ga = torch.zeros(4,K,device=dev); gb = torch.zeros(N,4,device=dev)
-        tf, kf = run(lambda: nat.lora_linear_fwd(x,w,None,a,b,1.0))
-        tb, kb = run(lambda: nat.lora_linear_bwd_input(dy,wt,a,b,1.0,True))
-        tg, kg = run(lambda: nat.lora_linear_bwd_params(dy,x,t,u,ga,gb,1.0))
-        fl = 2.0*M*K*N; by = 2.0*(M*K+N*K+M*N); bg = 2.0*(M*N+M*K)
-        line = f"{M:6d}x{K:5d}x{N:6d} fwd {tf:7.1f}us {fl/tf/1e6:6.0f}TF {by/tf/1e3:6.0f}GB/s [{kf[0][18:28]}] | bwd {tb:7.1f}us {fl/tb/1e6:6.0f}TF [{kb[0][18:28]}] | grad {tg:6.1f}us {bg/tg/1e3:6.0f}GB/s"
+        tf, _, kf = run(lambda: nat.lora_linear_fwd(x,w,None,a,b,1.0))
+        tb, _, kb = run(lambda: nat.lora_linear_bwd_input(dy,wt,a,b,1.0,True))
+        fl = 2.0*M*K*N; by = 2.0*(M*K+N*K+M*N)
+        line = f"{M:6d}x{K:5d}x{N:6d} fwd {tf:7.1f}us {fl/tf/1e6:6.0f}TF {by/tf/1e3:6.0f}GB/s [{kf[0][18:28]}] | bwd {tb:7.1f}us {fl/tb/1e6:6.0f}TF [{kb[0][18:28]}]"
         if "--ref" in sys.argv:
             e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
             for _ in range(5): torch.nn.functional.linear(x,w)
@@ -36,4 +35,63 @@ def main():
             e1.record(); torch.cuda.synchronize()
             line += f" | hipblaslt(host-timed) {e0.elapsed_time(e1)/50*1e3:6.1f}us"
         print(line, flush=True)
-main()
+def grouped():
+    """q/k/v as one launch (block-diagonal rank 12) vs three; all 32 context K/V projections as one launch vs 32."""
+    dtype = torch.float16
+    for (M,K,N) in [(16384,320,320),(4096,640,640),(1024,1280,1280),(256,1280,1280)]:
+        G, r = 3, 4
+        x = torch.randn(M,K,device=dev).to(dtype); w = (torch.randn(G*N,K,device=dev)/K**0.5).to(dtype); wt = w.t().contiguous()
+        dy = torch.randn(M,G*N,device=dev).to(dtype)
+        Fa = torch.zeros(16,K,device=dev,dtype=dtype); Fa[:12] = torch.randn(12,K,device=dev).to(dtype)/4
+        Qb = torch.zeros(G*N,16,device=dev,dtype=dtype); Fb = torch.zeros(16,G*N,device=dev,dtype=dtype); Qa = Fa.t().contiguous()
+        for g in range(G):
+            blk = (torch.randn(N,r,device=dev)*0.05).to(dtype); Qb[g*N:(g+1)*N, g*r:(g+1)*r] = blk; Fb[g*r:(g+1)*r, g*N:(g+1)*N] = blk.t()
+        y = torch.empty(M,G*N,device=dev,dtype=dtype); t = torch.empty(M,12,device=dev); dx = torch.empty(M,K,device=dev,dtype=dtype); u = torch.empty(M,12,device=dev)
+        tf, _, kf = run(lambda: nat.lora_gemm_packed(x,K,w,None,Fa,Qb,None,None,0,y,t,M,K,G*N,12,1.0))
+        tb, _, kb = run(lambda: nat.lora_gemm_packed(dy,G*N,wt,None,Fb,Qa,None,None,0,dx,u,M,G*N,K,12,1.0))
+        by = 2.0*(M*K+G*N*K+M*G*N)
+        print(f"qkv {M:6d}x{K:5d}x3*{N:5d} fwd {tf:7.1f}us {by/tf/1e3:6.0f}GB/s [{kf[0][18:28]}] | bwd {tb:7.1f}us {by/tb/1e3:6.0f}GB/s [{kb[0][18:28]}]", flush=True)
+    M, K, r = 308, 768, 4
+    widths = [320]*10 + [640]*10 + [1280]*12
+    total = sum(widths); G = len(widths)
+    x = torch.randn(M,K,device=dev).to(dtype); w = (torch.randn(total,K,device=dev)/K**0.5).to(dtype)
+    A16 = (torch.randn(G*16,K,device=dev)/4).to(dtype); B16 = (torch.randn(total,16,device=dev)*0.05).to(dtype); Bt16 = (torch.randn(16*total,device=dev)*0.05).to(dtype)
+    tp, offs, o = [], [], 0
+    for i, n in enumerate(widths):
+        tp += [i | (1 << 16)] + [i]*(n//64-1); offs.append(o); o += n
+    tile_part = torch.tensor(tp,dtype=torch.int32).to(dev)
+    pt = torch.tensor([[offs[i], widths[i], 16*offs[i], i*M*r] for i in range(G)],dtype=torch.int64).to(dev)
+    Y = torch.empty(M,total,device=dev,dtype=dtype); T = torch.empty(G,M,r,device=dev); U = torch.empty(G,M,r,device=dev); dY = torch.randn(M,total,device=dev).to(dtype)
+    tf, _, kf = run(lambda: nat.lora_gemm_packed(x,K,w,None,A16,B16,tile_part,None,G,Y,T,M,K,total,r,1.0))
+    tb, _, kb = run(lambda: nat.lora_gemm_packed(dY,total,None,None,Bt16,None,None,pt,G,None,U,M,64,0,r,1.0,work_cols=total))
+    by = 2.0*(M*K+total*K+M*total)
+    print(f"ctx-kv group {M}x{K}x{total} fwd {tf:7.1f}us {by/tf/1e3:6.0f}GB/s [{kf[0][18:28]}] | U-only bwd {tb:7.1f}us {2.0*M*total/tb/1e3:6.0f}GB/s [{kb[0][18:28]}]", flush=True)
+def grads():
+    """All 288 factor-gradient problems of one SD1.5 cfg-2 step in one lora_grad_batched call (+ the fold)."""
+    dtype = torch.float16
+    layers = [(16384,320,320)]*30 + [(16384,320,2560)]*5 + [(308,768,320)]*10 + [(4096,640,640)]*30 + [(4096,640,5120)]*5 + [(308,768,640)]*10 + [(1024,1280,1280)]*30 + [(1024,1280,10240)]*5 + [(308,768,1280)]*12 + [(256,1280,1280)]*6 + [(256,1280,10240)]*1
+    r = 4
+    total = sum(r*(K+N) for _,K,N in layers); stride = (total+3)//4*4
+    partials = torch.empty(nat.GRAD_MAX_BLOCKS, stride, device=dev); grads_ = torch.zeros(stride, device=dev)
+    cache = {}
+    def buf(M, C):
+        if (M,C) not in cache: cache[(M,C)] = [torch.randn(M,C,device=dev).to(dtype) for _ in range(3)]
+        return cache[(M,C)]
+    probs, ranges, keep, off, nbytes = [], [], [], 0, 0
+    for i,(M,K,N) in enumerate(layers):
+        dy = buf(M,N)[i%3]; x = buf(M,K)[(i+1)%3]; t = torch.randn(M,r,device=dev); u = torch.randn(M,r,device=dev)
+        keep += [t,u]
+        probs.append(nat.grad_problem(dy,0,N,N,t,0,r,r,[partials.data_ptr()+4*off],r,False,stride,M,1.0))
+        probs.append(nat.grad_problem(x,0,K,K,u,0,r,r,[partials.data_ptr()+4*(off+N*r)],r,True,stride,M,1.0))
+        ranges.append([off, r*(K+N), nat.grad_row_blocks(M), 0]); off += r*(K+N); nbytes += 2.0*M*(K+N)
+    table = torch.tensor(ranges,dtype=torch.int64).to(dev)
+    d0 = torch.device(dev,0)
+    tg, nl, kg = run(lambda: nat.lora_grad_batched(probs, dtype, d0), iters=10)
+    e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
+    nat.lora_fold_partials(table,len(ranges),max(r_[1] for r_ in ranges),partials,stride,grads_,True); torch.cuda.synchronize(); e0.record()
+    for _ in range(20): nat.lora_fold_partials(table,len(ranges),max(r_[1] for r_ in ranges),partials,stride,grads_,True)
+    e1.record(); torch.cuda.synchronize()
+    print(f"batched grads: {len(probs)} problems, {nl:.0f} launches, {tg:8.1f} us per step ({nbytes/tg/1e3:6.0f} GB/s algorithmic) | fold {e0.elapsed_time(e1)/20*1e3:6.1f} us (host-timed)", flush=True)
+if "--grouped" in sys.argv: grouped()
+elif "--grads" in sys.argv: grads()
+else: per_shape()
