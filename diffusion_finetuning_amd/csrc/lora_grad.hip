@@ -45,11 +45,15 @@ struct GradBatch {
 };
 static_assert(sizeof(GradBatch) <= 4096, "kernel arguments are limited to 4 KB");
 
+constexpr int kChunkRows = 256;  // rows of P staged in LDS at a time
+
 template <typename T, int RP /* padded rank: 4, 8, 16 */>
 __global__ __launch_bounds__(256) void lora_grad_kernel(const GradBatch p) {
     constexpr int VEC = ElemTraits<T>::kVec;
-    constexpr int UNROLL = RP >= 16 ? 4 : 8;  // rows in flight per thread (the P rows cost RP registers each)
-    extern __shared__ __attribute__((aligned(16))) float sred[];
+    constexpr int UNROLL = RP >= 16 ? 4 : 8;  // rows in flight per thread
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    float* sred = smem_f;                           // [row groups][4][strip] — the cross-row-group reduction image
+    float* sP = smem_f + 256 * 4 * VEC;             // [kChunkRows][RP]      — the P rows of the current row chunk
 
     // which problem does this workgroup belong to: linear scan of ≤ 28 prefix sums held in SGPRs
     int it = 0;
@@ -80,31 +84,45 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(const GradBatch p) {
     const int64_t m_begin = (int64_t)rb * q.rows_per_block;
     int64_t m_end = m_begin + q.rows_per_block;
     if (m_end > q.M) m_end = q.M;
+    const T* S = static_cast<const T*>(q.S) + c0 + c_local;
 
-    if (active && m_begin < m_end) {
-        const T* S = static_cast<const T*>(q.S) + c0 + c_local;
-        const int64_t last = m_end - 1;
-        for (int64_t m = m_begin + rsub; m < m_end; m += (int64_t)rows_pp * UNROLL) {
-            // UNROLL independent rows per trip; loads are unconditional from clamped rows (a load under
-            // a per-lane condition is branched around and waited for one by one), tails are zero-weighted
-            Chunk<T> s[UNROLL];
-            float pv[UNROLL][RP];
+    for (int64_t mc = m_begin; mc < m_end; mc += kChunkRows) {  // wave-uniform trip count
+        const int rows = (int)min((int64_t)kChunkRows, m_end - mc);
+        // P rows of this chunk → LDS, zero-padded to RP columns: the row loop then reads them as 16-byte broadcasts
+        // instead of RP scalar global loads per row (which out-numbered the S loads 4:1 … 16:1 in the issue stream)
+        __syncthreads();
+        for (int i = tid; i < rows * RP; i += 256) {
+            const int row = i / RP, j = i - row * RP;
+            sP[i] = j < r ? q.P[(mc + row) * q.p_stride + j] : 0.f;
+        }
+        __syncthreads();
+        if (active) {
+            const int last = rows - 1;
+            for (int m = rsub; m < rows; m += rows_pp * UNROLL) {
+                // UNROLL independent rows per trip; loads are unconditional from clamped rows (a load under
+                // a per-lane condition is branched around and waited for one by one), tails are zero-weighted
+                Chunk<T> s[UNROLL];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const int64_t mu = m + (int64_t)u * rows_pp;
-                const int64_t ml = mu < m_end ? mu : last;
-                s[u] = *reinterpret_cast<const Chunk<T>*>(S + ml * q.s_stride);
+                for (int u = 0; u < UNROLL; ++u) {
+                    const int mu = m + u * rows_pp;
+                    const int ml = mu < rows ? mu : last;
+                    s[u] = *reinterpret_cast<const Chunk<T>*>(S + (mc + ml) * q.s_stride);
+                }
 #pragma unroll
-                for (int j = 0; j < RP; ++j) pv[u][j] = q.P[ml * q.p_stride + (j < r ? j : r - 1)];
-            }
+                for (int u = 0; u < UNROLL; ++u) {
+                    const int mu = m + u * rows_pp;
+                    const bool ok = mu < rows;
+                    const float4* prow = reinterpret_cast<const float4*>(sP + (ok ? mu : last) * RP);
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const bool ok = m + (int64_t)u * rows_pp < m_end;
+                    for (int j4 = 0; j4 < RP / 4; ++j4) {
+                        const float4 pv = prow[j4];
+                        const float w[4] = {ok ? pv.x : 0.f, ok ? pv.y : 0.f, ok ? pv.z : 0.f, ok ? pv.w : 0.f};
 #pragma unroll
-                for (int j = 0; j < RP; ++j) {
-                    const float w = (ok && j < r) ? pv[u][j] : 0.f;
+                        for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) acc[j][e] = fmaf(to_f32<T>(s[u].v[e]), w, acc[j][e]);
+                            for (int e = 0; e < VEC; ++e)
+                                acc[j4 * 4 + jj][e] = fmaf(to_f32<T>(s[u].v[e]), w[jj], acc[j4 * 4 + jj][e]);
+                    }
                 }
             }
         }
@@ -246,7 +264,7 @@ bool plan_item(GradItem& q, int nb) {
 template <typename T>
 int launch_batch(const GradBatch& b, int rp, hipStream_t stream) {
     constexpr int VEC = ElemTraits<T>::kVec;
-    const int lds = 256 * 4 * VEC * 4;  // [row groups][4][strip] floats, one 4-column slab at a time
+    const int lds = 256 * 4 * VEC * 4 + kChunkRows * rp * 4;  // reduction image + the staged P rows
     const dim3 grid((unsigned)b.first_block[b.n]);
     switch (rp) {
         case 4: LORA_LAUNCH(PK_GRAD_R4, (lora_grad_kernel<T, 4>), grid, dim3(256), lds, stream, b); break;

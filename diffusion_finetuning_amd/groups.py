@@ -102,8 +102,7 @@ class _QKVProjFn(torch.autograd.Function):
             x2 = x2.to(cdtype)
         if not x2.is_contiguous():
             x2 = x2.contiguous()
-        need_wt = torch.is_grad_enabled() and x.requires_grad
-        w, wt = group.frozen.get(cdtype, need_wt)
+        w, wt = group.frozen.get(cdtype, ctx.needs_input_grad[0])  # Wᵀ only when a dX launch will follow
         M = x2.shape[0]
         qkv = torch.empty((M, N3), dtype=cdtype, device=x2.device)
         t = torch.empty((M, rr), dtype=torch.float32, device=x2.device)

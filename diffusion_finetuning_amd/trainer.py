@@ -543,8 +543,9 @@ class LoraTrainer:
                 return self._step_eager(latents, noise, timesteps, ehs, prior, prior_weight, None, seed,
                                         early_bucket=False)
             self._graph = st
-            # the warm-up passes left valid partial sums of THIS step's inputs, but replay once so that every step
-            # (including the first) is produced by the same recorded kernels
+            # the warm-up passes each folded this step's gradients into the slab: clear it, then replay once so that
+            # every step (including the first) is produced by the same recorded kernels
+            self.slab.zero_grad()
         else:
             self._graph_inputs(st, latents, noise, timesteps, ehs, seed)
         st["graph"].replay()
