@@ -141,15 +141,22 @@ def measured_traffic(kernel_name, dtype):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/*pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE
     doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950).  PMC counters cannot be read from inside the
-    process, so this is the newest committed measurement, or null."""
+    process, so this is the newest committed measurement — and only if it was taken from the very sources the
+    loaded library was built from (digest of csrc/ + header, stamped by tools/summarize_profile.py); otherwise null."""
     import glob
     import re
+
+    from diffusion_finetuning_amd import build_native
 
     m = re.search(r"<\*, (\d+), (\d+), (true|false)>", kernel_name)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
     if not files or dtype != "f16":
         return None
     table = json.load(open(files[-1]))
+    stamp = os.path.join(build_native.LIB_DIR, "liblora_hip.stamp")
+    built_from = open(stamp).read().strip() if os.path.exists(stamp) else None
+    if not built_from or table.get("_csrc_digest") != built_from:
+        return None
     if m:
         prefix = f"lora_gemm_kernel<DF16_,{m.group(1)},{m.group(2)},{1 if m.group(3) == 'true' else 0}"
     else:
@@ -246,7 +253,8 @@ def main():
         log(f"model + {len(data)} synthetic batches resident on {torch.cuda.get_device_name(local_rank)}; priming")
     # Setup, not measurement: one throw-away step on a scratch copy of the LoRA state so that MIOpen / hipBLASLt /
     # SDPA pick (and, on a box with a cold cache, search for) their kernels before the W warm-up steps start.
-    snapshot = (trainer.slab.params.clone(), trainer.opt.exp_avg.clone(), trainer.opt.exp_avg_sq.clone(), trainer.opt.step_count)
+    snapshot = (trainer.slab.params.clone(), trainer.opt.exp_avg.clone(), trainer.opt.exp_avg_sq.clone(), trainer.opt.step_count,
+                trainer.opt.norm.clone())
     want_graph, trainer.capture_graph = trainer.capture_graph, False
     trainer.step(*data[0])  # host-launched: solver searches and lazy initialisation happen here
     torch.cuda.synchronize()
@@ -281,6 +289,7 @@ def main():
                 f"{'hipGraph' if trainer.capture_graph else 'host-launched'}")
     trainer.slab.params.copy_(snapshot[0]); trainer.opt.exp_avg.copy_(snapshot[1]); trainer.opt.exp_avg_sq.copy_(snapshot[2])
     trainer.opt.step_count = snapshot[3]
+    trainer.opt.norm.copy_(snapshot[4])  # incl. the device-side count of applied steps
     del snapshot
     if rank == 0:
         log("warm-up")

@@ -69,8 +69,13 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* g, int64_
         t = block_sum_256(t, s_wave);
         f = block_sum_256(f, s_wave);
         if (threadIdx.x == 0) {
+            const bool overflow = f != 0.f || !isfinite(t);
             norm_out[0] = t;
-            norm_out[1] = (f != 0.f || !isfinite(t)) ? 1.f : 0.f;
+            norm_out[1] = overflow ? 1.f : 0.f;
+            // applied-step counter for the bias corrections (exact in fp32 up to 2^24 steps): a skipped step does not
+            // count, exactly as GradScaler does not call optimizer.step() on overflow; [3] counts the skipped ones
+            if (overflow) norm_out[3] += 1.f;
+            else norm_out[2] += 1.f;
         }
     }
 }
@@ -83,7 +88,7 @@ struct AdamParams {
     int64_t n;
     const float* norm_in;
     float grad_mul, max_norm, lr, beta1, beta2, eps, wd;
-    float bc1, bc2_sqrt;  // 1-β1^t, sqrt(1-β2^t)
+    float bc1, bc2_sqrt;  // 1-β1^t, sqrt(1-β2^t); bc1 <= 0: compute them from the device step counter norm_in[2]
 };
 
 // torch.optim.AdamW (single-tensor path) per element, in this order:
@@ -98,8 +103,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamParams a) {
             clip = c < 1.f ? c : 1.f;
         }
     }
+    float bc1 = a.bc1, bc2_sqrt = a.bc2_sqrt;
+    if (bc1 <= 0.f) {  // device-resident step count (wave-uniform branch): same double arithmetic as the host path
+        const double t = (double)a.norm_in[2];
+        bc1 = (float)(1.0 - pow((double)a.beta1, t));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)a.beta2, t));
+    }
     const float gm = a.grad_mul * clip;
-    const float step_size = a.lr / a.bc1;
+    const float step_size = a.lr / bc1;
     const float decay = 1.f - a.lr * a.wd;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
         const float g = a.g[i] * gm;
@@ -107,7 +118,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamParams a) {
         float m = a.m[i];
         m = m + (g - m) * (1.f - a.beta1);
         const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
-        const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+        const float denom = sqrtf(v) / bc2_sqrt + a.eps;
         p = p - step_size * (m / denom);
         a.p[i] = p;
         a.m[i] = m;
@@ -248,14 +259,15 @@ extern "C" int lora_grad_sqnorm(const float* grad, int64_t n, float grad_mul, fl
 extern "C" int lora_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                                const float* norm_in, float grad_mul, float max_norm, float lr, float beta1,
                                float beta2, float eps, float weight_decay, int step, void* stream) {
-    if (!param || !grad || !exp_avg || !exp_avg_sq || n < 1 || step < 1) return LORA_E_BADARG;
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n < 1 || step < 0) return LORA_E_BADARG;
+    if (step == 0 && !norm_in) return LORA_E_BADARG;  // step 0 = "use the device counter norm_in[2]"
     AdamParams a{};
     a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = n; a.norm_in = norm_in;
     a.grad_mul = grad_mul; a.max_norm = max_norm; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2;
     a.eps = eps; a.wd = weight_decay;
     // bias corrections in double on the host, as torch does with python floats
-    a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
-    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    a.bc1 = step > 0 ? (float)(1.0 - pow((double)beta1, (double)step)) : 0.f;
+    a.bc2_sqrt = step > 0 ? (float)sqrt(1.0 - pow((double)beta2, (double)step)) : 0.f;
     int64_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);

@@ -287,7 +287,10 @@ class FusedClipAdamW:
         self.step_count = 0
 
     def step(self, grad_mul: float = 1.0):
-        """One optimizer step on the current gradient slab; `grad_mul` = 1/(world_size·loss_scale)."""
+        """One optimizer step on the current gradient slab; `grad_mul` = 1/(world_size·loss_scale).  `step_count` counts
+        calls (it keys the on-device noise draw, which the reference also advances every iteration); the bias
+        corrections use the number of APPLIED steps, kept on the device (`norm[2]`): an overflowed step is skipped and
+        does not count, like torch.cuda.amp.GradScaler never calls optimizer.step() for it."""
         s = self.slab
         self.step_count += 1
         nat.lora_grad_sqnorm(s.grads[: s.numel], grad_mul, self.norm)
@@ -297,7 +300,7 @@ class FusedClipAdamW:
                 continue
             nat.lora_adamw_step(s.params[a:b], s.grads[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], self.norm,
                                 grad_mul, self.max_grad_norm, g["lr"], self.betas[0], self.betas[1], self.eps,
-                                g.get("weight_decay", 1e-2), self.step_count)
+                                g.get("weight_decay", 1e-2), 0)
 
     def grad_norm(self) -> float:
         """Total (pre-clip) gradient L2 norm of the last step (host sync)."""
@@ -305,6 +308,13 @@ class FusedClipAdamW:
 
     def overflowed(self) -> bool:
         return bool(self.norm[1].item() != 0.0)
+
+    def applied_steps(self) -> int:
+        """Optimizer steps that really updated the parameters (host sync)."""
+        return int(self.norm[2].item())
+
+    def skipped_steps(self) -> int:
+        return int(self.norm[3].item())
 
 
 class SlabExchange:
@@ -392,6 +402,8 @@ class LoraTrainer:
         self.device = self.slab.params.device
         self.dtype = next(p for p in unet.parameters() if p.dim() == 4).dtype  # conv weight dtype = compute dtype
         self.loss_scale = float(loss_scale) if loss_scale is not None else (1024.0 if self.dtype == torch.float16 else 1.0)
+        self._initial_scale, self._clean_steps, self._flag_event, self._warned_overflow = self.loss_scale, 0, None, False
+        self._flag_host = torch.zeros(1, dtype=torch.float32).pin_memory() if self.loss_scale != 1.0 else None
         self.slab.enable_packed(self.dtype)
         self.v_prediction = v_prediction
         self.sqrt_acp, self.sqrt_1macp = ddpm_tables(device=self.device)
@@ -431,6 +443,45 @@ class LoraTrainer:
 
         mid.register_full_backward_hook(early)
 
+    # -- loss scale (fp16) ---------------------------------------------------------------------------
+    GROWTH_INTERVAL = 2000  # torch.cuda.amp.GradScaler's default
+
+    def _watch_overflow(self):
+        """Ship the step's overflow flag to pinned host memory without waiting for it."""
+        if self._flag_host is not None and self._flag_event is None:
+            self._flag_host.copy_(self.opt.norm[1:2], non_blocking=True)
+            self._flag_event = torch.cuda.Event()
+            self._flag_event.record()
+
+    def _poll_overflow(self):
+        """GradScaler's scale update, one or two steps late and without a host sync: an overflowed (hence skipped) step
+        halves the loss scale, GROWTH_INTERVAL clean steps double it again (never above the initial value).  A changed
+        scale is picked up by the next step; a recorded hipGraph is re-recorded (the scale is baked into it)."""
+        ev = self._flag_event
+        if ev is None or not ev.query():
+            return
+        self._flag_event = None
+        if float(self._flag_host[0]) != 0.0:
+            self.loss_scale = max(1.0, self.loss_scale * 0.5)
+            self._clean_steps = 0
+            if not self._warned_overflow:
+                self._warned_overflow = True
+                import warnings
+
+                warnings.warn(f"LoraTrainer: non-finite fp16 gradients — the step was skipped and the loss scale "
+                              f"lowered to {self.loss_scale:g} (GradScaler semantics)")
+        else:
+            self._clean_steps += 1
+            if self._clean_steps >= self.GROWTH_INTERVAL and self.loss_scale < self._initial_scale:
+                self.loss_scale, self._clean_steps = min(self._initial_scale, self.loss_scale * 2.0), 0
+
+    def _fingerprint(self):
+        """Everything a recorded step has baked in besides the shapes: scalars passed as kernel arguments and the
+        addresses / versions of the frozen operands the caches hand to the kernels."""
+        layers = self.slab.layers
+        return (self.loss_scale, self.v_prediction, tuple(float(l.scale) for l in layers),
+                tuple((l.linear.weight.data_ptr(), l.linear.weight._version) for l in layers))
+
     # -- one step ---------------------------------------------------------------------------------
     def step(self, latents, noise, timesteps, encoder_hidden_states, *, with_prior_preservation=False,
              prior_loss_weight=1.0, mask=None, seed: Optional[int] = None):
@@ -438,6 +489,7 @@ class LoraTrainer:
         latents) and `timesteps` (int64 [B]) — the caller drew them, as the reference does — or pass None for both and
         a `seed`: the step then draws them on the device (Philox keyed by (seed, optimizer step), identical on
         every rank) inside the prologue kernel."""
+        self._poll_overflow()
         if self.capture_graph and mask is None and self.text_encoder is None:
             return self._step_graph(latents, noise, timesteps, encoder_hidden_states, with_prior_preservation,
                                     prior_loss_weight, seed)
@@ -473,6 +525,7 @@ class LoraTrainer:
         self.slab.flush()  # factor gradients of every layer that ran: batched launch + ordered fold into the slab
         self.exchange.finish()
         self.opt.step(grad_mul=1.0 / (self.world * self.loss_scale))
+        self._watch_overflow()
         self.slab.repack()  # forwards outside step() (sampling, evaluation, saving merged weights) see the new factors
         return loss
 
@@ -513,9 +566,11 @@ class LoraTrainer:
 
     def _step_graph(self, latents, noise, timesteps, ehs, prior, prior_weight, seed):
         key = (tuple(latents.shape), tuple(ehs.shape), bool(prior), float(prior_weight), noise is None)
+        fp = self._fingerprint()
         st = self._graph
-        if st is None or st["key"] != key:
-            st = {"key": key, "draw": noise is None, "prior": bool(prior), "prior_weight": float(prior_weight),
+        if st is None or st["key"] != key or st["fp"] != fp:
+            self._graph = st = None  # drop the old recording (and the operand buffers it pins) before making a new one
+            st = {"key": key, "fp": fp, "draw": noise is None, "prior": bool(prior), "prior_weight": float(prior_weight),
                   "latents": torch.empty_like(latents, dtype=torch.float32),
                   "noise": torch.empty_like(latents, dtype=torch.float32),
                   "timesteps": torch.empty(latents.shape[0], dtype=torch.int64, device=self.device),
@@ -551,6 +606,7 @@ class LoraTrainer:
         st["graph"].replay()
         self.exchange.finish()
         self.opt.step(grad_mul=1.0 / (self.world * self.loss_scale))
+        self._watch_overflow()
         self.slab.repack()
         return st["loss"].clone()
 

@@ -226,11 +226,16 @@ int lora_cast_matrix(const void* src, void* dst, int64_t rows, int64_t cols, int
  * Fused clip_grad_norm_ + AdamW over the flat LoRA slab —
  * training_scripts/train_lora_dreambooth.py:878-888 (clip_grad_norm_(…, max_grad_norm); optimizer.step())
  * and lora_diffusion/cli_lora_pti.py:448-451.
- *   lora_grad_sqnorm : norm_out[0] = Σ (grad_mul·g)² over n elements (deterministic two-level sum),
- *                      norm_out[1] = 1.0f if any element is non-finite else 0.0f.
+ *   lora_grad_sqnorm : norm_out (4 floats, device; zero it once before the first step):
+ *                      [0] = Σ (grad_mul·g)² over n elements (deterministic two-level sum),
+ *                      [1] = 1.0f if any element is non-finite else 0.0f,
+ *                      [2] += 1 when [1] == 0: the number of APPLIED optimizer steps including this one,
+ *                      [3] += 1 when [1] != 0: the number of skipped steps.
  *   lora_adamw_step  : g' = grad_mul·g·min(1, max_norm/(sqrt(norm_in[0])+1e-6))   (max_norm<=0: no clip)
- *                      torch.optim.AdamW update (decoupled weight decay, bias correction with `step`),
- *                      skipped entirely when norm_in[1] != 0 (GradScaler-style overflow skip).
+ *                      torch.optim.AdamW update (decoupled weight decay, bias correction with `step`, or with
+ *                      the device counter norm_in[2] when step == 0), skipped entirely when norm_in[1] != 0 —
+ *                      torch.cuda.amp.GradScaler semantics: an overflowed step neither moves the parameters nor
+ *                      advances the optimizer's step count.
  * `grad_mul` carries 1/world_size (mean all-reduce) and 1/loss_scale.
  */
 int lora_grad_sqnorm(const float* grad, int64_t n, float grad_mul, float* norm_out, void* workspace,

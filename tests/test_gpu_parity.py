@@ -274,6 +274,57 @@ def test_clip_adamw_against_oracle(relerr):
     assert norm[1].item() == 1.0 and torch.equal(p, before)
 
 
+def test_overflow_skip_follows_gradscaler_and_torch_adamw(relerr):
+    """GradScaler semantics end to end on the device: an overflowed step leaves parameters, moments AND the step
+    count alone (torch's scaler does not call optimizer.step()), so after [ok, inf, ok, nan, ok] the state equals
+    torch.optim.AdamW stepped three times — bias corrections come from the device counter norm[2] (step = 0)."""
+    g = torch.Generator().manual_seed(8)
+    n, lr, scale = 4099, 1e-3, 1024.0
+    p0 = torch.randn(n, generator=g)
+    p_ref = torch.nn.Parameter(p0.clone())
+    ref = torch.optim.AdamW([p_ref], lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    p, m, v = p0.to(DEV).clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    norm = torch.zeros(4, device=DEV)
+    for kind in ("ok", "inf", "ok", "nan", "ok"):
+        grad = torch.randn(n, generator=g)
+        scaled = (grad * scale).to(DEV)  # what backward leaves in the slab: loss-scaled gradients
+        if kind != "ok":
+            scaled[123] = float(kind)
+        else:
+            p_ref.grad = grad.clone()
+            torch.nn.utils.clip_grad_norm_([p_ref], 1.0)
+            ref.step()
+        nat.lora_grad_sqnorm(scaled, 1.0 / scale, norm)
+        nat.lora_adamw_step(p, scaled, m, v, norm, 1.0 / scale, 1.0, lr, 0.9, 0.999, 1e-8, 1e-2, 0)
+        assert (norm[1].item() != 0.0) == (kind != "ok")
+    assert norm[2].item() == 3.0 and norm[3].item() == 2.0
+    assert int(ref.state[p_ref]["step"]) == 3
+    assert relerr(p, p_ref.detach()) < 1e-6
+    assert relerr(m, ref.state[p_ref]["exp_avg"]) < 1e-5 and relerr(v, ref.state[p_ref]["exp_avg_sq"]) < 1e-4
+
+
+def test_trainer_backs_the_loss_scale_off_after_an_overflow(tiny_unet_factory):
+    """fp16 trainer: a step whose gradients overflow is skipped, reported once, and the loss scale is halved for the
+    following steps (picked up without a host sync, so at most two steps late)."""
+    import warnings
+
+    unet = tiny_unet_factory(seed=3).to(DEV).half()
+    params, _ = dfa.inject_trainable_lora(unet, r=4)
+    _warm(list(itertools.chain(*params)), 11, 0.02)
+    trainer = tr.LoraTrainer(unet, lr=1e-3, loss_scale=2.0 ** 30)  # absurd scale: the first steps must overflow
+    before = tr.flat_lora_state(unet).clone()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        for step in range(40):
+            lat, noise, ts, ctx = orc.synthetic_batch(step, 2, 8, 6, 32)
+            trainer.step(lat.to(DEV), noise.to(DEV), ts.to(DEV), ctx.to(DEV))
+            torch.cuda.synchronize()
+    assert trainer.opt.skipped_steps() >= 1 and trainer.opt.applied_steps() >= 1
+    assert trainer.opt.skipped_steps() + trainer.opt.applied_steps() == 40 == trainer.opt.step_count
+    assert trainer.loss_scale < 2.0 ** 30 and any("loss scale" in str(x.message) for x in w)
+    assert not torch.equal(tr.flat_lora_state(unet), before) and torch.isfinite(tr.flat_lora_state(unet)).all()
+
+
 def test_add_noise_against_oracle(relerr):
     g = torch.Generator().manual_seed(4)
     x0, eps = torch.randn(4, 4, 16, 16, generator=g), torch.randn(4, 4, 16, 16, generator=g)
