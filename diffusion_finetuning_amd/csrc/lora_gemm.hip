@@ -139,7 +139,7 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sQ = smem + kStages * STAGE;
-    float* sP = reinterpret_cast<float*>(smem);  // epilogue overlay: [2][BM][16]
+    float* sP = reinterpret_cast<float*>(smem);  // epilogue overlay: [NW/2][BM][kSPS] (ring kernels: a free ring buffer)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -250,19 +250,20 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
         }
     }
 
-    // bias of the lane's 4·NI output columns, fetched now so the epilogue never waits on it
+    // bias of the lane's 4·NI output columns (4 consecutive columns per fragment: ONE 8-/16-byte load each), fetched
+    // now so the epilogue never waits on it
     float bias_v[MAIN ? NI : 1][4];
     if constexpr (MAIN) {
         if (p.bias != nullptr) {
             const T* bias = static_cast<const T*>(p.bias);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
+            for (int ni = 0; ni < NI; ++ni) {
+                int col = n0 + wn * WTN + ni * 16 + lq * 4;
+                if (col > p.Nc - 4) col = p.Nc - 4;  // Nc % VEC == 0 here: a group of 4 is inside or past the edge
+                const Quad<T> q = *reinterpret_cast<const Quad<T>*>(bias + col);
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    int col = n0 + wn * WTN + ni * 16 + lq * 4 + reg;
-                    if (col > p.Nc - 1) col = p.Nc - 1;
-                    bias_v[ni][reg] = to_f32<T>(bias[col]);
-                }
+                for (int reg = 0; reg < 4; ++reg) bias_v[ni][reg] = to_f32<T>(q.v[reg]);
+            }
         }
     }
     STAMP(13);
@@ -343,6 +344,7 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
     };
 
     const int nk = (Kc + BK - 1) / BK;
+    int buf = 0;  // ring position: after the loop, the buffer that would be filled next — i.e. a FREE one
     if constexpr (PIPE) {
         // ---- LDS-DMA ring.  Lane (row, physical chunk c') fetches logical chunk c' ^ (row & 7): the DMA
         // writes lane-linearly, so the swizzle lives on the source address and on the fragment reads.
@@ -366,7 +368,6 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
         for (int i = 0; i < DIST; ++i)
             if (i < nk) issue(i, i);
         STAMP(2);
-        int buf = 0;
         for (int kt = 0; kt < nk; ++kt) {
             // stage kt has landed for this wave once only the loads of the stages issued after it are outstanding:
             // `ahead` of them, L loads each (L + 1 on the two waves that also fetch the factor rows)
@@ -451,7 +452,15 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
 
     STAMP(4);
     // ---- epilogue 1: combine the two partial P tiles through LDS --------------------------
-    __syncthreads();
+    // Ring kernels put the P image into the ring buffer that is FREE after the last step (nothing in flight, last
+    // read one step ago behind a barrier) and, for 16-bit types, the C tile into the buffer of the last step (free
+    // once every wave has passed the barrier below): two workgroup barriers in the whole epilogue instead of four.
+    constexpr bool FREEBUF = PIPE;
+    constexpr bool FASTC = PIPE && MAIN && !F32;
+    static_assert(!FREEBUF || (NW / 2) * BM * kSPS * 4 <= STAGE, "P image must fit one ring buffer");
+    char* const last_buf = smem + (buf == 0 ? kStages - 1 : buf - 1) * STAGE;
+    if constexpr (FREEBUF) sP = reinterpret_cast<float*>(smem + buf * STAGE);
+    else __syncthreads();
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int row = wm * (BM / 2) + mi * 16 + l15;
@@ -553,10 +562,12 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
         constexpr int ROWS = BM / EP;
         constexpr int SC_STRIDE = BN * (int)sizeof(T) + 16;
         constexpr int CPR = BN / VEC;  // 16-B chunks per tile row
+        static_assert(!FASTC || ROWS * SC_STRIDE <= STAGE, "C tile must fit one ring buffer");
+        char* const sC = FASTC ? last_buf : smem;
         T* Cg = static_cast<T*>(p.C);
 #pragma unroll
         for (int ep = 0; ep < EP; ++ep) {
-            __syncthreads();  // sP / sQ (or the previous pass) are dead
+            if constexpr (!FASTC) __syncthreads();  // sP / sQ (or the previous pass) are dead
             if (EP == 1 || wm == ep) {
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
@@ -568,7 +579,7 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
                         Quad<T> q;
 #pragma unroll
                         for (int reg = 0; reg < 4; ++reg) q.v[reg] = from_f32<T>(acc[mi][ni][reg]);
-                        *reinterpret_cast<Quad<T>*>(smem + row * SC_STRIDE + col * (int)sizeof(T)) = q;
+                        *reinterpret_cast<Quad<T>*>(sC + row * SC_STRIDE + col * (int)sizeof(T)) = q;
                     }
             }
             __syncthreads();
@@ -580,7 +591,7 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
             for (int i = 0; i < NST; ++i) {
                 const int idx = tid + i * NT;
                 const int row = idx / CPR, ch = idx - row * CPR;
-                out[i] = *reinterpret_cast<const Chunk<T>*>(smem + row * SC_STRIDE + ch * 16);
+                out[i] = *reinterpret_cast<const Chunk<T>*>(sC + row * SC_STRIDE + ch * 16);
             }
 #pragma unroll
             for (int i = 0; i < NST; ++i) {
@@ -750,10 +761,9 @@ int launch_pipe(const GemmParams& p, hipStream_t stream) {
     bool deep = tiles64 < 512;
     if (forced_tile() == 0) big = true;
     if (forced_tile() == 2) big = false;
-    static const int nw_env = [] { const char* e = getenv("LORA_FORCE_WAVES"); return e ? atoi(e) : 0; }();
     if (big) {
         if (stg_env == 3) return launch_tile<T, 128, 128, true, 3>(p, stream);
-        return nw_env == 8 ? launch_tile<T, 128, 128, true, 2, 8>(p, stream) : launch_tile<T, 128, 128, true, 2, 4>(p, stream);
+        return launch_tile<T, 128, 128, true, 2, 4>(p, stream);
     }
     if (stg_env == 2) deep = false;
     if (stg_env == 3) deep = true;
