@@ -57,7 +57,10 @@ SIGNATURES = {
     "lora_grad_batched": (_i32, [ctypes.POINTER(GradProblem), _i32, _i32, _vp]),
     "lora_fold_partials": (_i32, [_vp, _i32, _i64, _vp, _i64, _vp, _i32, _vp]),
     "lora_gemm_packed": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _f32,
-                                _i64, _i32, _vp]),
+                                _i64, _vp, _i64, _i32, _vp]),
+    "lora_gemm_workspace_bytes": (_i64, [_i64, _i32, _i32, _i32]),
+    "lora_linear_bwd_input_ws": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp,
+                                        _i64, _vp]),
     "lora_pack_items": (_i32, [_vp, _i32, _i32, _vp, _vp, _i32, _vp]),
     "ddpm_mse_fwd_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i64, _i64, _f32, _f32, _vp, _vp, _vp, _i32, _vp]),
     "lora_mse_workspace_bytes": (_i64, []),
@@ -228,12 +231,26 @@ def lora_linear_bwd_input(dy2, wt, a, b, scale: float, need_dx: bool, packs=None
         packs = lora_pack_factors(a, b, dy2.dtype)
     dx = torch.empty((M, K), dtype=dy2.dtype, device=dy2.device) if need_dx else None
     u = torch.empty((M, r), dtype=torch.float32, device=dy2.device)
+    ws = _splitk_workspace(M, N, K, dy2) if need_dx else None
     _check(
-        lib().lora_linear_bwd_input(_ptr(dy2), _ptr(wt), _ptr(a), _ptr(b), _ptr(packs[0]), _ptr(packs[1]), _ptr(dx),
-                                    _ptr(u), M, K, N, r, float(scale), dtype_code(dy2.dtype), _stream(dy2)),
+        lib().lora_linear_bwd_input_ws(_ptr(dy2), _ptr(wt), _ptr(a), _ptr(b), _ptr(packs[0]), _ptr(packs[1]), _ptr(dx),
+                                       _ptr(u), M, K, N, r, float(scale), dtype_code(dy2.dtype), _ptr(ws),
+                                       0 if ws is None else ws.numel() * 4, _stream(dy2)),
         "lora_linear_bwd_input",
     )
     return dx, u
+
+
+_ws_bytes_cache = {}
+
+
+def _splitk_workspace(M: int, Kc: int, Nc: int, like):
+    """fp32 scratch for a contraction the library wants to split over K (None when it does not)."""
+    key = (M, Kc, Nc, like.dtype)
+    nbytes = _ws_bytes_cache.get(key)
+    if nbytes is None:
+        nbytes = _ws_bytes_cache[key] = int(lib().lora_gemm_workspace_bytes(M, Kc, Nc, dtype_code(like.dtype)))
+    return torch.empty(nbytes // 4, dtype=torch.float32, device=like.device) if nbytes > 0 else None
 
 
 def grad_blocks_for(M: int) -> int:
@@ -312,9 +329,11 @@ def lora_gemm_packed(am, lda: int, bm, bias, fp, qp, tile_part, part_table, n_pa
     """C = Am·Bmᵀ + bias + s·P·Qᵀ, P = Am·Fᵀ on packed factors (include/lora_hip.h: lora_gemm_packed).  All operands
     are device tensors (or None); nothing is allocated here."""
     _require_device(am, bm, bias, fp, qp, tile_part, part_table, c, p_out)
+    ws = _splitk_workspace(M, Kc, Nc, am) if (c is not None and tile_part is None) else None
     _check(lib().lora_gemm_packed(_ptr(am), int(lda), _ptr(bm), _ptr(bias), _ptr(fp), _ptr(qp), _ptr(tile_part),
                                   _ptr(part_table), int(n_parts), _ptr(c), _ptr(p_out), int(M), int(Kc), int(Nc), int(r),
-                                  float(scale), int(work_cols), dtype_code(am.dtype), _stream(am)), "lora_gemm_packed")
+                                  float(scale), int(work_cols), _ptr(ws), 0 if ws is None else ws.numel() * 4,
+                                  dtype_code(am.dtype), _stream(am)), "lora_gemm_packed")
 
 
 def lora_reduce_partials(partials, part_stride: int, n_blocks: int, grads, n: int, accumulate: bool) -> None:

@@ -56,6 +56,12 @@ struct GemmParams {
     //         into P} — blockIdx covers (row tile, part), every part contracts its own column range of Am.
     const int* tile_part;
     const int64_t* part_table;
+    // Split-K (long contractions on grids too small for the chip): slice s of a tile contracts K-steps
+    // [s·steps_per_slice, …) and STORES its fp32 partial tile at ws_c[s][M][Nc] and its partial P at ws_p[s][M][16];
+    // splitk_reduce_kernel then adds the slices in order, the bias and the rank-r term.  splitk <= 1: off.
+    int splitk, steps_per_slice;
+    float* ws_c;
+    float* ws_p;
 };
 
 constexpr int kRowBytes = 128;  // one K-step of one tile row
@@ -103,32 +109,34 @@ __device__ unsigned long long g_stamps[8192 * 16];
 
 // One stage of the ring / the single staging buffer: A rows, B rows, 16 factor rows.  Only the first two waves load the
 // factor rows, so they carry one more DMA per stage than the others: the counted waits are picked per wave.
-template <int BM, int BN, bool MAIN, int STG, int NW> constexpr int stage_bytes() {
+template <int BM, int BN, bool MAIN, int STG, int NW> constexpr int stage_bytes() {  // (same for every wave layout)
     return (BM + (MAIN ? BN : 0) + kRP) * kRowBytes;
 }
-template <int BM, int BN, typename T, bool MAIN, int STG, int NW> constexpr int gemm_lds_bytes() {
+template <int BM, int BN, typename T, bool MAIN, int STG, int NW, int WM> constexpr int gemm_lds_bytes() {
     constexpr int ring = (STG > 0 ? STG : 1) * stage_bytes<BM, BN, MAIN, STG, NW>();
     constexpr int sq = MAIN ? BN * kRP * (int)sizeof(T) : 0;
     constexpr int ep = sizeof(T) == 4 ? 2 : 1;
-    constexpr int sc = MAIN ? (BM / ep) * (BN * (int)sizeof(T) + 16) : 0;
-    constexpr int sp = (NW / 2) * BM * kSPS * 4;
+    constexpr int sc = (MAIN && STG == 0) || (MAIN && sizeof(T) == 4) ? (BM / ep) * (BN * (int)sizeof(T) + 16) : 0;
+    constexpr int sp = (NW / WM) * BM * kSPS * 4;
     constexpr int a = ring + sq;
     constexpr int b = sc > sp ? sc : sp;
     return a > b ? a : b;
 }
 
 // STG: LDS ring depth of the DMA pipeline (2 or 3); 0 selects the register-staged fallback loop.
-template <typename T, int BM, int BN, bool MAIN, int STG, int NW>
+// NW waves as WM row waves × NW/WM column waves; every wave owns a (BM/WM) × (BN·WM/NW) piece of the tile.
+template <typename T, int BM, int BN, bool MAIN, int STG, int NW, int WM>
 __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
     constexpr bool PIPE = STG > 0;
     constexpr int kStages = PIPE ? STG : 1;
     constexpr int NT = NW * 64;        // threads
-    constexpr int WN = NW / 2;         // column waves (row waves: 2)
+    constexpr int WN = NW / WM;        // column waves
     constexpr int WTN = BN / WN;       // wave tile width
     constexpr int RPP = NW * 8;        // tile rows covered by one staging pass
     constexpr int VEC = ElemTraits<T>::kVec;
     constexpr int BK = kRowBytes / (int)sizeof(T);
-    constexpr int MI = BM / 32;  // 16-row fragments per wave
+    constexpr int WTM = BM / WM;       // wave tile height
+    constexpr int MI = WTM / 16;  // 16-row fragments per wave
     constexpr int NI = WTN / 16;
     constexpr int PA = BM / RPP;  // staging passes
     constexpr int PB = BN / RPP;
@@ -162,14 +170,19 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
     // Pull every kernel argument into SGPRs now: one scalar-load round trip instead of two dependent ones.
     asm volatile("" ::"s"(p.Am), "s"(p.Bm), "s"(p.bias), "s"(p.Fp), "s"(p.Qp), "s"(p.C), "s"(p.P), "s"(p.M), "s"(p.Kc),
                  "s"(p.Nc), "s"(p.scale), "s"(p.tiles_m), "s"(p.tiles_n), "s"(p.col_major), "s"(p.lda), "s"(p.tile_part),
-                 "s"(p.part_table));
-    int tile;
+                 "s"(p.part_table), "s"(p.splitk), "s"(p.steps_per_slice), "s"(p.ws_c), "s"(p.ws_p));
+    int tile, slice = 0;
     {
-        const int total = p.tiles_m * p.tiles_n;
+        const int S = p.splitk > 1 ? p.splitk : 1;
+        const int total = p.tiles_m * p.tiles_n * S;
         const int id = blockIdx.x;
         const int q = total >> 3, rem = total & 7;
         const int xcd = id & 7, slot = id >> 3;
         tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
+        if (S > 1) {  // the slices of one tile are neighbours: they read the same operand rows, a K-range each
+            slice = tile % S;
+            tile = tile / S;
+        }
     }
     // Which operand should stay inside one XCD's L2?  Row-major tile order keeps a row panel of Am there and makes
     // every XCD stream all of Bm; column-major order keeps a slice of Bm there and streams Am instead.  The host
@@ -290,7 +303,7 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
                 Frag af[MI];
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
-                    af[mi] = *reinterpret_cast<const Frag*>(sA + lds_off(wm * (BM / 2) + mi * 16 + l15, chunk));
+                    af[mi] = *reinterpret_cast<const Frag*>(sA + lds_off(wm * WTM + mi * 16 + l15, chunk));
                 if ((kt * 2 + ks) % WN == wn) {
                     const Frag ff = *reinterpret_cast<const Frag*>(sF + lds_off(l15, chunk));
 #pragma unroll
@@ -316,7 +329,7 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
                 f32x4 af[MI];
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
-                    af[mi] = *reinterpret_cast<const f32x4*>(sA + lds_off(wm * (BM / 2) + mi * 16 + l15, chunk));
+                    af[mi] = *reinterpret_cast<const f32x4*>(sA + lds_off(wm * WTM + mi * 16 + l15, chunk));
                 if ((kt * 2 + h) % WN == wn) {
                     const f32x4 ff = *reinterpret_cast<const f32x4*>(sF + lds_off(l15, chunk));
 #pragma unroll
@@ -343,7 +356,9 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
         }
     };
 
-    const int nk = (Kc + BK - 1) / BK;
+    int nk = (Kc + BK - 1) / BK;
+    const int kt0 = slice * p.steps_per_slice;  // first K-step of this workgroup (0 unless split-K)
+    if (p.splitk > 1) nk = nk - kt0 < p.steps_per_slice ? nk - kt0 : p.steps_per_slice;
     int buf = 0;  // ring position: after the loop, the buffer that would be filled next — i.e. a FREE one
     if constexpr (PIPE) {
         // ---- LDS-DMA ring.  Lane (row, physical chunk c') fetches logical chunk c' ^ (row & 7): the DMA
@@ -354,7 +369,7 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
         const int wave_rows = wave * 8 * kRowBytes;
         auto issue = [&](int kt, int buf) {
             char* st = smem + buf * STAGE + wave_rows;
-            const int k0 = kt * BK + src_off;
+            const int k0 = (kt0 + kt) * BK + src_off;
 #pragma unroll
             for (int i = 0; i < PA; ++i) glds16(a_ptr[i] + k0, st + RPP * i * kRowBytes);
             if constexpr (MAIN) {
@@ -440,12 +455,12 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
             }
             if (ld_row < kRP) *reinterpret_cast<Chunk<T>*>(smem + OFF_F + lds_off(ld_row, ld_chunk)) = rfc;
         };
-        load_step(0);
+        load_step(kt0 * BK);
         for (int kt = 0; kt < nk; ++kt) {
             if (kt > 0) __syncthreads();
             store_step();
             __syncthreads();
-            if (kt + 1 < nk) load_step((kt + 1) * BK);
+            if (kt + 1 < nk) load_step((kt0 + kt + 1) * BK);
             compute(smem, kt);
         }
     }
@@ -457,17 +472,49 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
     // once every wave has passed the barrier below): two workgroup barriers in the whole epilogue instead of four.
     constexpr bool FREEBUF = PIPE;
     constexpr bool FASTC = PIPE && MAIN && !F32;
-    static_assert(!FREEBUF || (NW / 2) * BM * kSPS * 4 <= STAGE, "P image must fit one ring buffer");
+    static_assert(!FREEBUF || WN * BM * kSPS * 4 <= STAGE, "P image must fit one ring buffer");
     char* const last_buf = smem + (buf == 0 ? kStages - 1 : buf - 1) * STAGE;
     if constexpr (FREEBUF) sP = reinterpret_cast<float*>(smem + buf * STAGE);
     else __syncthreads();
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        const int row = wm * (BM / 2) + mi * 16 + l15;
+        const int row = wm * WTM + mi * 16 + l15;
         *reinterpret_cast<f32x4*>(&sP[(wn * BM + row) * kSPS + lq * 4]) = pacc[mi];
     }
     __syncthreads();
 
+    if (p.splitk > 1) {
+        // this slice's partial sums: P (all 16 rank slots, first column tile only) and the fp32 accumulators, straight
+        // from the registers (a lane owns 4 consecutive columns: 16-byte stores)
+        if (tn == 0) {
+            const int half = tid & 1;
+            for (int row = tid >> 1; row < BM && m0 + row < p.M; row += NT / 2) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v[e] = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WN; ++w) v[e] += sP[(w * BM + row) * kSPS + half * 8 + e];
+                }
+                float* dst = p.ws_p + ((int64_t)slice * p.M + m0 + row) * kRP + half * 8;
+                *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            }
+        }
+        if constexpr (MAIN) {
+            float* wc = p.ws_c + (int64_t)slice * p.M * p.Nc;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int64_t m = m0 + wm * WTM + mi * 16 + l15;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int col = n0 + wn * WTN + ni * 16 + lq * 4;
+                    if (m < p.M && col < p.Nc) *reinterpret_cast<f32x4*>(wc + m * p.Nc + col) = acc[mi][ni];
+                }
+            }
+        }
+        return;
+    }
     if (write_p) {
         const int half = tid & 1;
         for (int row = tid >> 1; row < BM && m0 + row < p.M; row += NT / 2) {
@@ -501,7 +548,7 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
                 f32x4 pimg[MG][WN][2];
 #pragma unroll
                 for (int i = 0; i < MG; ++i) {
-                    const int row = wm * (BM / 2) + (mg + i) * 16 + l15;
+                    const int row = wm * WTM + (mg + i) * 16 + l15;
 #pragma unroll
                     for (int w = 0; w < WN; ++w) {
                         const f32x4* src = reinterpret_cast<const f32x4*>(&sP[(w * BM + row) * kSPS + j0]);
@@ -536,7 +583,7 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
                 for (int ni = 0; ni < NI; ++ni) qv[ni] = q[(wn * WTN + ni * 16 + l15) * kRP + j];
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
-                    const int row = wm * (BM / 2) + mi * 16 + l15;
+                    const int row = wm * WTM + mi * 16 + l15;
                     float pv = 0.f;
 #pragma unroll
                     for (int w = 0; w < WN; ++w) pv += sP[(w * BM + row) * kSPS + j];
@@ -558,23 +605,25 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) acc[mi][ni][reg] += bias_v[ni][reg];
         }
-        constexpr int EP = F32 ? 2 : 1;
-        constexpr int ROWS = BM / EP;
         constexpr int SC_STRIDE = BN * (int)sizeof(T) + 16;
+        // the C tile leaves in EP passes of ROWS rows (one pass when it fits the LDS area it is staged in)
+        constexpr int EP = F32 ? 2 : (FASTC && BM * SC_STRIDE > STAGE ? 2 : 1);
+        static_assert(WM % EP == 0, "a pass covers whole row waves");
+        constexpr int ROWS = BM / EP;
         constexpr int CPR = BN / VEC;  // 16-B chunks per tile row
         static_assert(!FASTC || ROWS * SC_STRIDE <= STAGE, "C tile must fit one ring buffer");
         char* const sC = FASTC ? last_buf : smem;
         T* Cg = static_cast<T*>(p.C);
 #pragma unroll
         for (int ep = 0; ep < EP; ++ep) {
-            if constexpr (!FASTC) __syncthreads();  // sP / sQ (or the previous pass) are dead
-            if (EP == 1 || wm == ep) {
+            if (!FASTC || ep > 0) __syncthreads();  // sP / sQ (or the previous pass) are dead
+            if (EP == 1 || wm / (WM / EP) == ep) {
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) {
                         // the lane owns 4 consecutive columns of one row: one 8-/16-byte LDS write
-                        const int row = (EP == 1 ? wm * (BM / 2) : 0) + mi * 16 + l15;
+                        const int row = (EP == 1 ? wm : wm % (WM / EP)) * WTM + mi * 16 + l15;
                         const int col = wn * WTN + ni * 16 + lq * 4;
                         Quad<T> q;
 #pragma unroll
@@ -687,6 +736,123 @@ __global__ __launch_bounds__(256) void pack_factors_batched_kernel(const int64_t
                 blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
+// Second half of a split-K launch: C[m,n] = T( Σ_s ws_c[s][m][n] + bias[n] + scale·Σ_j P[m][j]·Q[n][j] ),
+// P[m][j] = Σ_s ws_p[s][m][j] (also written out, unscaled).  Slices are added in index order: deterministic.
+// A workgroup owns 16 rows × 128 columns (blockIdx.y = column block); thread = 8 consecutive columns of one row.
+// S is a template parameter so that all slice loads of a trip are in flight together (a run-time loop waits for each).
+template <typename T, int S>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws_c, const float* ws_p, const void* bias_,
+                                                            const void* Qp_, void* C_, float* P_out, int64_t M, int Nc,
+                                                            int r, float scale) {
+    __shared__ float sPs[16][kRP];
+    const int64_t m0 = (int64_t)blockIdx.x * 16;
+    {
+        const int row = threadIdx.x >> 4, j = threadIdx.x & 15;  // 256 threads = 16 rows × 16 rank slots
+        const int64_t ml = m0 + row < M ? m0 + row : M - 1;
+        float part[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) part[s] = ws_p[((int64_t)s * M + ml) * kRP + j];
+        float v = 0.f;
+#pragma unroll
+        for (int s = 0; s < S; ++s) v += part[s];
+        sPs[row][j] = v;
+        if (blockIdx.y == 0 && P_out != nullptr && m0 + row < M && j < r) P_out[(m0 + row) * r + j] = v;
+    }
+    __syncthreads();
+    const T* bias = static_cast<const T*>(bias_);
+    const T* Qp = static_cast<const T*>(Qp_);
+    T* C = static_cast<T*>(C_);
+    const int cb = blockIdx.y * 128;                                  // first column of this block
+    const int chunks = (Nc - cb < 128 ? Nc - cb : 128) >> 3;          // Nc % 8 == 0 on this path
+    const int64_t slice = M * (int64_t)Nc;
+    for (int idx = threadIdx.x; idx < 16 * chunks; idx += 256) {
+        const int row = idx / chunks, c8 = cb + ((idx - row * chunks) << 3);
+        const int64_t m = m0 + row < M ? m0 + row : M - 1;  // clamped: rows past the end are computed, not stored
+        const float* src = ws_c + m * Nc + c8;
+        f32x4 a[S], b[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            a[s] = *reinterpret_cast<const f32x4*>(src + s * slice);
+            b[s] = *reinterpret_cast<const f32x4*>(src + s * slice + 4);
+        }
+        float q[8][kRP];
+        if constexpr (sizeof(T) == 2) {  // the 8 packed rows of Q (16 values each) as 16-byte loads
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const Chunk<T> lo = *reinterpret_cast<const Chunk<T>*>(Qp + (int64_t)(c8 + e) * kRP);
+                const Chunk<T> hi = *reinterpret_cast<const Chunk<T>*>(Qp + (int64_t)(c8 + e) * kRP + 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    q[e][j] = to_f32<T>(lo.v[j]);
+                    q[e][8 + j] = to_f32<T>(hi.v[j]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int j = 0; j < kRP; ++j) q[e][j] = to_f32<T>(Qp[(int64_t)(c8 + e) * kRP + j]);
+        }
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[e] += a[s][e];
+                acc[4 + e] += b[s][e];
+            }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float l = 0.f;
+#pragma unroll
+            for (int j = 0; j < kRP; ++j) l = fmaf(sPs[row][j], q[e][j], l);  // unused rank slots of Q are zero
+            acc[e] += scale * l;
+            if (bias != nullptr) acc[e] += to_f32<T>(bias[c8 + e]);
+        }
+        if (m0 + row >= M) continue;
+        T* dst = C + m * Nc + c8;
+        if constexpr (sizeof(T) == 2) {
+            Chunk<T> out;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) out.v[e] = from_f32<T>(acc[e]);
+            *reinterpret_cast<Chunk<T>*>(dst) = out;
+        } else {
+            *reinterpret_cast<f32x4*>(dst) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+        }
+    }
+}
+
+template <typename T>
+void launch_splitk_reduce(const GemmParams& p, int S, hipStream_t stream) {
+    const dim3 grid((unsigned)((p.M + 15) / 16), (unsigned)((p.Nc + 127) / 128));
+#define SK_CASE(S_)                                                                                            \
+    case S_:                                                                                                   \
+        LORA_LAUNCH(PK_OTHER, (splitk_reduce_kernel<T, S_>), grid, dim3(256), 0, stream, p.ws_c, p.ws_p, p.bias, p.Qp, p.C, \
+                    p.P, p.M, p.Nc, p.r, p.scale);                                                             \
+        break;
+    switch (S) { SK_CASE(2) SK_CASE(3) SK_CASE(4) SK_CASE(5) SK_CASE(6) SK_CASE(7) SK_CASE(8) default: break; }
+#undef SK_CASE
+}
+
+// Split-K plan: only for long contractions whose 128×128 grid cannot fill the chip.  Returns the slice count (1 = off).
+int plan_splitk(int64_t M, int Kc, int Nc, int esize) {
+    static const int env = [] { const char* e = getenv("LORA_SPLITK"); return e ? atoi(e) : -1; }();
+    if (env == 0) return 1;
+    const int nk = (Kc * esize + kRowBytes - 1) / kRowBytes;
+    const int64_t tiles = ((M + 127) / 128) * ((Nc + 127) / 128);
+    // measured (tools/gemm_bench.py): wins from 64 K-steps up (GEGLU proj backward, 80 / 160 K-steps: 62→52, 72→54,
+    // 69→35 µs); at 30 / 60 K-steps (grouped q/k/v backward) the second launch costs what the split gains
+    if (nk < 64 || tiles > 192 || (Nc & 7) != 0 || (Kc * esize) % kRowBytes != 0) return 1;
+    int S = (int)((384 + tiles - 1) / tiles);  // aim at ~1.5 workgroups per CU
+    if (S > 8) S = 8;
+    while (S > 1 && nk / S < 8) --S;           // keep >= 8 K-steps per slice: below that the fixed phases dominate
+    if (env > 1) S = env > 8 ? 8 : env;
+    return S;
+}
+
 // Generalised packing for grouped layers: one table row per FACTOR,
 //   {src_off, which (0: A [r,len] / 1: B [len,r]), len, r, d16_off, d16_ld, dT_off, rows}
 // writes rows j < `rows` of the [16,len] form at packed[d16_off + j·d16_ld + c] and/or columns j < `rows` of the [len,16]
@@ -709,23 +875,29 @@ __global__ __launch_bounds__(256) void pack_items_kernel(const int64_t* table, c
     }
 }
 
-template <typename T, int BM, int BN, bool MAIN, int STG, int NW = 4>
+template <typename T, int BM, int BN, bool MAIN, int STG, int NW = 4, int WM = 2>
 int launch_tile(GemmParams p, hipStream_t stream) {
     p.tiles_m = (int)((p.M + BM - 1) / BM);
     p.tiles_n = MAIN ? (p.Nc + BN - 1) / BN : (p.part_table ? p.tiles_n : 1);  // skinny grouped: tiles_n = parts
     static const int order_env = [] { const char* e = getenv("LORA_FORCE_COLMAJOR"); return e ? atoi(e) : -1; }();
     p.col_major = order_env >= 0 ? order_env : (MAIN && (int64_t)p.Nc > p.M ? 1 : 0);
-    constexpr int lds = gemm_lds_bytes<BM, BN, T, MAIN, STG, NW>();
-    auto kern = lora_gemm_kernel<T, BM, BN, MAIN, STG, NW>;
+    constexpr int lds = gemm_lds_bytes<BM, BN, T, MAIN, STG, NW, WM>();
+    auto kern = lora_gemm_kernel<T, BM, BN, MAIN, STG, NW, WM>;
     if (lds > 48 * 1024) {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (attr != hipSuccess) return LORA_E_LAUNCH;
     }
-    constexpr int prof_id = MAIN ? (BM == 256 ? PK_GEMM_256x128 : (BM == 128 ? PK_GEMM_128x128 : PK_GEMM_64x64))
+    constexpr int prof_id = MAIN ? (NW == 8 ? PK_GEMM_256x128 : (BM == 128 ? PK_GEMM_128x128 : PK_GEMM_64x64))
                                  : (BM == 128 ? PK_SKINNY_128 : PK_SKINNY_64);
-    LORA_LAUNCH(prof_id, kern, dim3(p.tiles_m * p.tiles_n), dim3(NW * 64), lds, stream, p);
+    const int S = p.splitk > 1 ? p.splitk : 1;
+    LORA_LAUNCH(prof_id, kern, dim3(p.tiles_m * p.tiles_n * S), dim3(NW * 64), lds, stream, p);
     LORA_LAUNCH_CHECK();
+    if (S > 1) {
+        lora_prof_set_work(0.0, 0.0);  // the reduction's time is recorded (kind "other"); its bytes are not algorithmic
+        launch_splitk_reduce<T>(p, S, stream);
+        LORA_LAUNCH_CHECK();
+    }
     return LORA_OK;
 }
 
@@ -750,6 +922,7 @@ template <typename T, bool MAIN>
 int launch_pipe(const GemmParams& p, hipStream_t stream) {
     if (!MAIN) return launch_tile<T, 64, 64, false, 3>(p, stream);
     static const int stg_env = [] { const char* e = getenv("LORA_FORCE_STAGES"); return e ? atoi(e) : 0; }();
+    if (p.splitk > 1) return launch_tile<T, 128, 128, true, 2>(p, stream);
     if (p.tile_part != nullptr) {  // grouped: 64-wide column tiles never straddle two parts
         const int64_t t64 = ((p.M + 63) / 64) * ((p.Nc + 63) / 64);
         return t64 < 512 ? launch_tile<T, 64, 64, true, 3>(p, stream) : launch_tile<T, 64, 64, true, 2>(p, stream);
@@ -761,7 +934,12 @@ int launch_pipe(const GemmParams& p, hipStream_t stream) {
     bool deep = tiles64 < 512;
     if (forced_tile() == 0) big = true;
     if (forced_tile() == 2) big = false;
+    // (8-wave workgroups — 128×256 as 2×4 waves, 256×128 as 4×2 waves, one per CU, 26 % fewer L2→LDS bytes per flop —
+    //  are supported by the template (WM parameter) and were measured: correct, 5–100 % slower on every hot-path shape,
+    //  e.g. 16384×320×2560 54 vs 50 µs; not instantiated.)
     if (big) {
+        // (a 3-stage ring on grids of <= 256 tiles — one workgroup per CU anyway — was measured: no gain, 12.8 → 13.6 µs on
+        //  4096×640×640; a lone workgroup is paced by the CU's vector-memory path issuing its own DMAs, not by latency)
         if (stg_env == 3) return launch_tile<T, 128, 128, true, 3>(p, stream);
         return launch_tile<T, 128, 128, true, 2, 4>(p, stream);
     }
@@ -801,6 +979,8 @@ struct CallArgs {  // what an entry point knows
     const int64_t* part_table; // grouped skinny launch
     int n_parts;
     bool packed_only;          // no fp32 masters behind Fp/Qp: the shape-agnostic kernels cannot run
+    void* workspace;           // optional fp32 scratch for split-K (lora_gemm_workspace_bytes)
+    int64_t ws_bytes;
 };
 
 template <typename T>
@@ -817,6 +997,17 @@ int launch_typed(const CallArgs& c, bool main_part, hipStream_t stream) {
         p.Am = c.Am; p.Bm = c.Bm; p.bias = c.bias; p.Fp = c.Fp; p.Qp = c.Qp;
         p.C = c.C; p.P = c.P; p.M = c.M; p.Kc = c.Kc; p.Nc = c.Nc; p.r = c.r; p.scale = c.scale;
         p.lda = lda; p.tile_part = c.tile_part; p.part_table = c.part_table; p.tiles_n = c.n_parts;
+        if (main_part && !grouped && c.workspace != nullptr && aligned16(c.workspace)) {
+            const int S = plan_splitk(c.M, c.Kc, c.Nc, (int)sizeof(T));
+            const int64_t need = (int64_t)S * c.M * ((int64_t)c.Nc + kRP) * 4;
+            if (S > 1 && c.ws_bytes >= need) {
+                const int nk = c.Kc / BK;
+                p.splitk = S;
+                p.steps_per_slice = (nk + S - 1) / S;
+                p.ws_c = static_cast<float*>(c.workspace);
+                p.ws_p = p.ws_c + (int64_t)S * c.M * c.Nc;
+            }
+        }
         if ((c.Kc % BK) == 0) return main_part ? launch_pipe<T, true>(p, stream) : launch_pipe<T, false>(p, stream);
         if (grouped) return LORA_E_UNSUPPORTED;  // grouped launches exist only on the LDS-DMA path
         return main_part ? launch_tile<T, 64, 64, true, 0>(p, stream) : launch_tile<T, 64, 64, false, 0>(p, stream);
@@ -969,9 +1160,22 @@ extern "C" int lora_linear_fwd(const void* X, const void* W, const void* bias, c
     return launch_gemm(c, true, dtype, s);
 }
 
+extern "C" int64_t lora_gemm_workspace_bytes(int64_t M, int Kc, int Nc, int dtype) {
+    if (M < 1 || Kc < 1 || Nc < 1) return 0;
+    const int S = plan_splitk(M, Kc, Nc, dtype == LORA_F32 ? 4 : 2);
+    return S > 1 ? (int64_t)S * M * ((int64_t)Nc + kRP) * 4 : 0;
+}
+
 extern "C" int lora_linear_bwd_input(const void* dY, const void* Wt, const float* A, const float* B,
                                      const void* Apack, const void* Bpack, void* dX, float* U_out, int64_t M, int K,
                                      int N, int r, float scale, int dtype, void* stream) {
+    return lora_linear_bwd_input_ws(dY, Wt, A, B, Apack, Bpack, dX, U_out, M, K, N, r, scale, dtype, nullptr, 0, stream);
+}
+
+extern "C" int lora_linear_bwd_input_ws(const void* dY, const void* Wt, const float* A, const float* B,
+                                        const void* Apack, const void* Bpack, void* dX, float* U_out, int64_t M, int K,
+                                        int N, int r, float scale, int dtype, void* workspace, int64_t ws_bytes,
+                                        void* stream) {
     const int st = check_common(M, K, N, r, dtype);
     if (st != LORA_OK) return st;
     if (M == 0) return LORA_OK;
@@ -986,6 +1190,7 @@ extern "C" int lora_linear_bwd_input(const void* dY, const void* Wt, const float
     c.Q = A; c.q_sn = 1; c.q_sj = K;               // Q[k,j] = A[j,k]
     c.C = dX; c.P = U_out;
     c.M = M; c.Kc = N; c.Nc = K; c.r = r; c.scale = scale;
+    c.workspace = workspace; c.ws_bytes = ws_bytes;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const double e = esize(dtype);
     const double bytes = dX ? e * ((double)M * N + (double)N * K + (double)M * K) + e * r * (K + N)
@@ -998,7 +1203,7 @@ extern "C" int lora_linear_bwd_input(const void* dY, const void* Wt, const float
 extern "C" int lora_gemm_packed(const void* Am, int64_t lda, const void* Bm, const void* bias, const void* Fp,
                                 const void* Qp, const int* tile_part, const int64_t* part_table, int n_parts, void* C,
                                 float* P_out, int64_t M, int Kc, int Nc, int r, float scale, int64_t work_cols,
-                                int dtype, void* stream) {
+                                void* workspace, int64_t ws_bytes, int dtype, void* stream) {
     if (M < 0 || Kc <= 0 || r < 1 || r > kRP) return LORA_E_BADARG;
     if (dtype != LORA_F32 && dtype != LORA_F16 && dtype != LORA_BF16) return LORA_E_BADARG;
     if (M == 0) return LORA_OK;
@@ -1010,6 +1215,7 @@ extern "C" int lora_gemm_packed(const void* Am, int64_t lda, const void* Bm, con
     c.Am = Am; c.Bm = Bm; c.bias = bias; c.Fp = Fp; c.Qp = Qp; c.C = C; c.P = P_out;
     c.M = M; c.Kc = Kc; c.Nc = main_part ? Nc : 1; c.r = r; c.scale = scale; c.lda = lda;
     c.tile_part = tile_part; c.part_table = part_table; c.n_parts = n_parts; c.packed_only = true;
+    c.workspace = workspace; c.ws_bytes = ws_bytes;
     const double e = esize(dtype);
     const double kc = work_cols > 0 ? (double)work_cols : (double)Kc;
     ProfWork work(main_part ? e * ((double)M * Kc + (double)Nc * Kc + (double)M * Nc) + e * r * (double)(Kc + Nc) +

@@ -586,7 +586,11 @@ class LoraTrainer:
                         self._graph_body(st)
                 torch.cuda.current_stream().wait_stream(side)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # With a process group alive, its watchdog thread polls HIP events every now and then; under the default
+                # "global" capture mode such a call from ANOTHER thread invalidates the recording (a race that shows up
+                # in a few percent of the captures).  "thread_local" keeps the check for this thread only.
+                mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+                with torch.cuda.graph(g, capture_error_mode=mode):
                     self._graph_body(st)
                 st["graph"] = g
             except Exception as exc:  # keep training: this trainer falls back to eager steps for good

@@ -98,6 +98,18 @@ int lora_linear_fwd(const void* X, const void* W, const void* bias /* nullable *
 int lora_linear_bwd_input(const void* dY, const void* Wt, const float* A, const float* B,
                           const void* Apack, const void* Bpack, void* dX /* nullable */, float* U_out,
                           int64_t M, int K, int N, int r, float scale, int dtype, void* stream);
+/*
+ * The same with caller-provided scratch for split-K: a long contraction on a grid too small for the chip (the GEGLU
+ * `proj` backward: dX[1024,1280] = dY[1024,10240]·W — 80 output tiles, 160 K-steps) is cut into K-slices that store
+ * fp32 partial tiles, and a second launch adds the slices in index order (deterministic), the bias and the rank-r term.
+ * lora_gemm_workspace_bytes(M, Kc, Nc, dtype) says how much scratch the contraction [M,Kc]·[Nc,Kc]ᵀ wants (0: the
+ * library would not split it); the workspace is only used during the call's launches (stream-ordered), 16-byte aligned.
+ */
+int64_t lora_gemm_workspace_bytes(int64_t M, int Kc, int Nc, int dtype);
+int lora_linear_bwd_input_ws(const void* dY, const void* Wt, const float* A, const float* B,
+                             const void* Apack, const void* Bpack, void* dX /* nullable */, float* U_out,
+                             int64_t M, int K, int N, int r, float scale, int dtype, void* workspace,
+                             int64_t ws_bytes, void* stream);
 
 /*
  * The fused kernel's own contract, for callers that hold PACKED factors only — grouped layers that share an input:
@@ -112,14 +124,15 @@ int lora_linear_bwd_input(const void* dY, const void* Wt, const float* A, const 
  *     Fp = [n_parts·16, Kc], P_out = [n_parts][M][r]); backward (no dX: the text encoder output is frozen) as one
  *     P-only launch with part_table[g] = {column offset into Am, contraction length, offset into Fp, offset into P_out}.
  * work_cols: Σ contraction lengths of a part_table launch (profiler accounting only; 0 = Kc).
+ * workspace / ws_bytes: optional split-K scratch (lora_gemm_workspace_bytes; NULL / 0 = never split).
  * Returns LORA_E_UNSUPPORTED when the operands are not 16-byte aligned / not a multiple of one K-step (grouping is
  * then simply not used by the caller).
  */
 int lora_gemm_packed(const void* Am, int64_t lda, const void* Bm /* nullable with C */, const void* bias /* nullable */,
                      const void* Fp, const void* Qp, const int* tile_part /* nullable, device */,
                      const int64_t* part_table /* nullable, device */, int n_parts, void* C /* nullable */,
-                     float* P_out, int64_t M, int Kc, int Nc, int r, float scale, int64_t work_cols, int dtype,
-                     void* stream);
+                     float* P_out, int64_t M, int Kc, int Nc, int r, float scale, int64_t work_cols,
+                     void* workspace /* nullable */, int64_t ws_bytes, int dtype, void* stream);
 
 /*
  * Backward w.r.t. the LoRA factors (no grad for W or b: lora.py:179-180 set requires_grad only on

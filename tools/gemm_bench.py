@@ -14,7 +14,10 @@ def run(fn, iters=20):
     torch.cuda.synchronize()
     res = nat.prof_collect(); nat.prof_enable(0)
     tot = sum(v["ms"] for v in res.values()); n = sum(v["launches"] for v in res.values())
-    return 1e3 * tot / iters, n / iters, list(res.keys())
+    keys = list(res.keys())
+    if "other" in res and len(res) > 1:  # split-K: show the reduction launch's share
+        keys = [k for k in keys if k != "other"] + [f"+reduce {1e3 * res['other']['ms'] / iters:.1f}us"]
+    return 1e3 * tot / iters, n / iters, keys
 def per_shape():
     dtype = torch.float16
     print("tile", os.environ.get("LORA_FORCE_TILE"), "stages", os.environ.get("LORA_FORCE_STAGES"))
@@ -26,7 +29,7 @@ def per_shape():
         tf, _, kf = run(lambda: nat.lora_linear_fwd(x,w,None,a,b,1.0))
         tb, _, kb = run(lambda: nat.lora_linear_bwd_input(dy,wt,a,b,1.0,True))
         fl = 2.0*M*K*N; by = 2.0*(M*K+N*K+M*N)
-        line = f"{M:6d}x{K:5d}x{N:6d} fwd {tf:7.1f}us {fl/tf/1e6:6.0f}TF {by/tf/1e3:6.0f}GB/s [{kf[0][18:28]}] | bwd {tb:7.1f}us {fl/tb/1e6:6.0f}TF [{kb[0][18:28]}]"
+        line = f"{M:6d}x{K:5d}x{N:6d} fwd {tf:7.1f}us {fl/tf/1e6:6.0f}TF {by/tf/1e3:6.0f}GB/s [{kf[0][18:28]}] | bwd {tb:7.1f}us {fl/tb/1e6:6.0f}TF [{kb[0][18:28]}] {kb[-1] if len(kb) > 1 else ''}"
         if "--ref" in sys.argv:
             e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
             for _ in range(5): torch.nn.functional.linear(x,w)
@@ -50,7 +53,7 @@ def grouped():
         tf, _, kf = run(lambda: nat.lora_gemm_packed(x,K,w,None,Fa,Qb,None,None,0,y,t,M,K,G*N,12,1.0))
         tb, _, kb = run(lambda: nat.lora_gemm_packed(dy,G*N,wt,None,Fb,Qa,None,None,0,dx,u,M,G*N,K,12,1.0))
         by = 2.0*(M*K+G*N*K+M*G*N)
-        print(f"qkv {M:6d}x{K:5d}x3*{N:5d} fwd {tf:7.1f}us {by/tf/1e3:6.0f}GB/s [{kf[0][18:28]}] | bwd {tb:7.1f}us {by/tb/1e3:6.0f}GB/s [{kb[0][18:28]}]", flush=True)
+        print(f"qkv {M:6d}x{K:5d}x3*{N:5d} fwd {tf:7.1f}us {by/tf/1e3:6.0f}GB/s [{kf[0][18:28]}] | bwd {tb:7.1f}us {by/tb/1e3:6.0f}GB/s [{kb[0][18:28]}] {kb[-1] if len(kb) > 1 else ''}", flush=True)
     M, K, r = 308, 768, 4
     widths = [320]*10 + [640]*10 + [1280]*12
     total = sum(widths); G = len(widths)
