@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel from the host each step instead of replaying the recorded hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=6, help="timed oracle steps of the CPU baseline (~3 s each on 16 cores)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --shared-gpu rehearses N ranks on one GPU")
     ap.add_argument("--shared-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--stub-body", default=None, choices=["ok", "fail"],

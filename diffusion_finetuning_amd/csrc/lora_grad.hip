@@ -47,10 +47,10 @@ static_assert(sizeof(GradBatch) <= 4096, "kernel arguments are limited to 4 KB")
 
 constexpr int kChunkRows = 256;  // rows of P staged in LDS at a time
 
-template <typename T, int RP /* padded rank: 4, 8, 16 */>
+template <typename T, int RP /* padded rank: 4, 8, 12, 16 */>
 __global__ __launch_bounds__(256) void lora_grad_kernel(const GradBatch p) {
     constexpr int VEC = ElemTraits<T>::kVec;
-    constexpr int UNROLL = RP >= 16 ? 4 : 8;  // rows in flight per thread
+    constexpr int UNROLL = RP >= 12 ? 4 : 8;  // rows in flight per thread
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     float* sred = smem_f;                           // [row groups][4][strip] — the cross-row-group reduction image
     float* sP = smem_f + 256 * 4 * VEC;             // [kChunkRows][RP]      — the P rows of the current row chunk
@@ -269,6 +269,7 @@ int launch_batch(const GradBatch& b, int rp, hipStream_t stream) {
     switch (rp) {
         case 4: LORA_LAUNCH(PK_GRAD_R4, (lora_grad_kernel<T, 4>), grid, dim3(256), lds, stream, b); break;
         case 8: LORA_LAUNCH(PK_GRAD_R8, (lora_grad_kernel<T, 8>), grid, dim3(256), lds, stream, b); break;
+        case 12: LORA_LAUNCH(PK_GRAD_R16, (lora_grad_kernel<T, 12>), grid, dim3(256), lds, stream, b); break;
         default: LORA_LAUNCH(PK_GRAD_R16, (lora_grad_kernel<T, 16>), grid, dim3(256), lds, stream, b); break;
     }
     LORA_LAUNCH_CHECK();
@@ -298,8 +299,8 @@ double problem_bytes(const lora_grad_problem& g, double e) {
 template <typename T>
 int run_problems(const lora_grad_problem* probs, int n, const int* n_blocks, hipStream_t stream) {
     const double e = sizeof(T);
-    for (int cls = 0; cls < 3; ++cls) {
-        const int rp = cls == 0 ? 4 : (cls == 1 ? 8 : 16);
+    for (int cls = 0; cls < 4; ++cls) {  // 12 = a grouped q/k/v gA at rank 4 (three rank groups in one pass over X)
+        const int rp = 4 * (cls + 1);
         GradBatch b;
         b.n = 0;
         b.first_block[0] = 0;
@@ -314,7 +315,7 @@ int run_problems(const lora_grad_problem* probs, int n, const int* n_blocks, hip
         };
         for (int i = 0; i < n; ++i) {
             const lora_grad_problem& g = probs[i];
-            const int want = g.r <= 4 ? 4 : (g.r <= 8 ? 8 : 16);
+            const int want = g.r <= 4 ? 4 : (g.r <= 8 ? 8 : (g.r <= 12 ? 12 : 16));
             if (g.r > 16) {
                 if (cls == 0) {
                     const int st = launch_generic<T>(g, n_blocks[i], stream);
