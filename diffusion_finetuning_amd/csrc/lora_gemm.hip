@@ -803,13 +803,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws_c, c
                 acc[e] += a[s][e];
                 acc[4 + e] += b[s][e];
             }
+        float bv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+        if (bias != nullptr) {
+            if constexpr (sizeof(T) == 2) {
+                const Chunk<T> bc = *reinterpret_cast<const Chunk<T>*>(bias + c8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bv[e] = to_f32<T>(bc.v[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bv[e] = to_f32<T>(bias[c8 + e]);
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float l = 0.f;
 #pragma unroll
             for (int j = 0; j < kRP; ++j) l = fmaf(sPs[row][j], q[e][j], l);  // unused rank slots of Q are zero
-            acc[e] += scale * l;
-            if (bias != nullptr) acc[e] += to_f32<T>(bias[c8 + e]);
+            acc[e] += scale * l + bv[e];
         }
         if (m0 + row >= M) continue;
         T* dst = C + m * Nc + c8;

@@ -16,6 +16,9 @@
 // 2×144 problems to lora_grad_batched at the end of backward — ~10 chip-filling launches instead of 144
 // latency-bound ones.  Operands may be strided views (a slice of a grouped projection's output) and the
 // rank columns of one problem may belong to several layers (grouped q/k/v: U is [M, 3r], three gA outputs).
+#include <algorithm>
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -299,6 +302,12 @@ double problem_bytes(const lora_grad_problem& g, double e) {
 template <typename T>
 int run_problems(const lora_grad_problem* probs, int n, const int* n_blocks, hipStream_t stream) {
     const double e = sizeof(T);
+    // biggest problems first: the launch then ends on small workgroups instead of on the tail of a 1-MB-per-block problem
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        return (double)probs[a].M * probs[a].C > (double)probs[b].M * probs[b].C;
+    });
     for (int cls = 0; cls < 4; ++cls) {  // 12 = a grouped q/k/v gA at rank 4 (three rank groups in one pass over X)
         const int rp = 4 * (cls + 1);
         GradBatch b;
@@ -313,7 +322,8 @@ int run_problems(const lora_grad_problem* probs, int n, const int* n_blocks, hip
             bytes = flops = 0.0;
             return st;
         };
-        for (int i = 0; i < n; ++i) {
+        for (int oi = 0; oi < n; ++oi) {
+            const int i = order[oi];
             const lora_grad_problem& g = probs[i];
             const int want = g.r <= 4 ? 4 : (g.r <= 8 ? 8 : (g.r <= 12 ? 12 : 16));
             if (g.r > 16) {

@@ -179,9 +179,10 @@ __global__ __launch_bounds__(256) void merge_batched_kernel(const int64_t* table
 template <typename T>
 __global__ __launch_bounds__(256) void lerp_kernel(T* x1, const T* x2, int64_t n, float a, float b) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const T p = from_f32<T>(a * to_f32<T>(x1[i]));
-        const T q = from_f32<T>(b * to_f32<T>(x2[i]));
-        x1[i] = from_f32<T>(to_f32<T>(p) + to_f32<T>(q));
+        // separately rounded products and sum, as three torch ops give them (no fma contraction for fp32 tensors)
+        const T p = from_f32<T>(__fmul_rn(a, to_f32<T>(x1[i])));
+        const T q = from_f32<T>(__fmul_rn(b, to_f32<T>(x2[i])));
+        x1[i] = from_f32<T>(__fadd_rn(to_f32<T>(p), to_f32<T>(q)));
     }
 }
 

@@ -136,9 +136,9 @@ def _warm(params, seed=11, std=0.02):
                 p.copy_((torch.randn(p.shape, generator=g) * std).to(p.device))
 
 
-def _train(grouped, hook, steps=4, dtype=torch.float32, graph=False, prior=False, batch=2):
+def _train(grouped, hook, steps=4, dtype=torch.float32, graph=False, prior=False, batch=2, r=4):
     unet = _tiny64().to(DEV).to(dtype)
-    params, _ = dfa.inject_trainable_lora(unet, r=4)
+    params, _ = dfa.inject_trainable_lora(unet, r=r)
     _warm(list(itertools.chain(*params)))
     if hook:
         set_use_memory_efficient_attention_xformers(unet, True)
@@ -171,6 +171,15 @@ def test_grouped_projections_follow_the_ungrouped_trajectory(relerr):
     ref_losses = orc.train_steps(ref, ref_params, 4, 2, 8, 6, 64, lr=1e-3)
     assert relerr(lg, torch.tensor(ref_losses)) < 5e-3
     assert relerr(got, orc.flat_params(ref_params)) < 5e-3
+
+
+def test_context_group_alone_at_rank_8(relerr):
+    """Rank 8 (cfg-3): 3·8 > 16 rank slots, so q/k/v stay three launches, but the context K/V group (own factor rows
+    per part) still applies — and follows the ungrouped trajectory."""
+    t_g, got, lg = _train(True, True, dtype=torch.float16, r=8)
+    assert not t_g.slab.qkv_groups and len(t_g.slab.ctx_groups) == 1 and t_g.slab.ctx_groups[0]._pass is not None
+    _, want, lu = _train(False, True, dtype=torch.float16, r=8)
+    assert relerr(lg, lu) < 2e-3 and relerr(got, want) < 2e-3, (relerr(lg, lu), relerr(got, want))
 
 
 def test_grouped_projections_with_prior_preservation_and_hipgraph(relerr):
@@ -233,11 +242,13 @@ def test_strided_attention_cores_equal_the_dense_ones(dtype):
         assert float(dkv[:, mask.to(DEV)].abs().max()) == 0.0  # nothing outside the two slices is written
 
 
-def test_grouped_context_projection_equals_per_layer_launches(close):
+@pytest.mark.parametrize("r,K", [(4, 768), (8, 768), (16, 1024), (1, 768)])
+def test_grouped_context_projection_equals_per_layer_launches(close, r, K):
     """lora_gemm_packed with tile_part (forward of 6 K/V projections of different widths in ONE launch) and with
-    part_table (their U = dY·B in one P-only launch) against lora_linear_fwd / lora_linear_bwd_input per layer."""
+    part_table (their U = dY·B in one P-only launch) against lora_linear_fwd / lora_linear_bwd_input per layer —
+    at the ranks / context widths of all BASELINE configs (r=4 SD1.5, r=8 cfg-3, r=16 + 1024-wide context SD2.1)."""
     g = torch.Generator().manual_seed(4)
-    dtype, K, r, M = torch.float16, 768, 4, 308
+    dtype, M = torch.float16, 308
     widths = [320, 320, 640, 640, 1280, 1280]
     total = sum(widths)
     x = torch.randn(M, K, generator=g).to(dtype).to(DEV)

@@ -226,6 +226,58 @@ def test_merge_against_reference_golden(golden_merge, relerr):
             assert relerr(m.to_out[0].weight.float(), t[f"merged_o.{tag}.a{alpha}"]) < tol
 
 
+def test_merge_of_a_cpu_resident_model_like_lora_add_upl(golden_merge):
+    """The reference's `lora_add` moves the pipeline to the CPU before merging (cli_lora_add.py:74-78, 92-96):
+    `weight_apply_lora` must take host-resident weights (staged through the HIP device, merged by the same kernel) and
+    hand back Parameters on the CPU, bit-identical to the device-resident merge; `loras` is consumed either way."""
+    t, meta = golden_merge
+    for dt in (torch.float32, torch.float16):
+        results = []
+        for where in ("cpu", DEV):
+            m = torch.nn.Module()
+            m.blk = type("CrossAttention", (torch.nn.Module,), {})()
+            m.blk.to_q = torch.nn.Linear(t["w_q"].shape[1], t["w_q"].shape[0], bias=False)
+            m.blk.to_out = torch.nn.ModuleList([torch.nn.Linear(t["w_o"].shape[1], t["w_o"].shape[0])])
+            with torch.no_grad():
+                m.blk.to_q.weight.copy_(t["w_q"])
+                m.blk.to_out[0].weight.copy_(t["w_o"])
+            m = m.to(dt).to(where)
+            loras = [t["up0"].clone(), t["down0"].clone(), t["up1"].clone(), t["down1"].clone()]
+            dfa.weight_apply_lora(m, loras, alpha=0.5)
+            assert loras == []
+            assert m.blk.to_q.weight.device.type == torch.device(where).type and m.blk.to_q.weight.dtype == dt
+            results.append((m.blk.to_q.weight.detach().cpu(), m.blk.to_out[0].weight.detach().cpu()))
+        assert torch.equal(results[0][0], results[1][0]) and torch.equal(results[0][1], results[1][1])
+
+
+def test_lerp_lora_lists_is_lora_add_lpl():
+    """`lerp_lora_lists` = the LoRA ⊕ LoRA interpolation of cli_lora_add.py:44-60, op-by-op in the tensors' dtype
+    (fp16 lists as `save_lora_weight` writes them).  fp32: bit-identical to the reference's torch expression on the CPU.
+    fp16: within one ulp — torch's own CPU half arithmetic is not the same on every host (the build container's CPU
+    agrees bit for bit with float-product-then-round, the GPU box's differs from it in 2 % of the elements by one ulp)."""
+    g = torch.Generator().manual_seed(12)
+    shapes = [(320, 4), (4, 320), (640, 4), (4, 768), (1280, 1), (1, 1280)]
+    for dtype in (torch.float16, torch.float32):
+        for alpha in (0.5, 0.3, 1.0):
+            l1 = [(torch.randn(s, generator=g) * 0.1).to(dtype) for s in shapes]
+            l2 = [(torch.randn(s, generator=g) * 0.1).to(dtype) for s in shapes]
+            want = [alpha * a + (1 - alpha) * b for a, b in zip(l1, l2)]  # the reference's expression, CPU torch
+            keep = list(l1)
+            out = dfa.lerp_lora_lists(l1, l2, alpha)
+            assert len(out) == len(shapes) and all(o is k for o, k in zip(out, keep))  # merged IN PLACE (x1.data = ...)
+            for o, w in zip(out, want):
+                assert o.device.type == "cpu" and o.dtype == dtype
+                if dtype == torch.float32:
+                    assert torch.equal(o, w)
+                else:
+                    ulp = torch.maximum(w.float().abs(), torch.tensor(6.1e-5)) * 2.0 ** -10  # >= one half-precision ulp
+                    assert ((o.float() - w.float()).abs() <= ulp).all()
+                    assert (o == w).float().mean().item() > 0.9
+    assert dfa.lerp_lora_lists([], [], 0.5) == []
+    with pytest.raises(RuntimeError, match="shape"):
+        dfa.lerp_lora_lists([torch.zeros(4, 2), torch.zeros(2, 4)], [torch.zeros(4, 3), torch.zeros(3, 4)], 0.5)
+
+
 def test_merge_equals_scaled_forward(relerr):
     """Ties a6 to a2: linear with W' = W + α·B·A equals the LoRA forward at scale α (merged UNet weights at α)."""
     torch.manual_seed(1)
