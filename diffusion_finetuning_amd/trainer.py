@@ -229,14 +229,15 @@ class LoraSlab:
     def defer(self, problem, layer_index, keep):
         """Queue one factor-gradient problem (a `_native.GradProblem`); `keep` = the tensors it reads, held until the
         launch; `layer_index` marks the layer whose slab range must be folded afterwards (None: covered by a sibling)."""
+        if layer_index is not None and layer_index in self._ran:
+            # the layer ran backward once more before a flush (gradient accumulation over micro-batches, a shared module):
+            # its partial-sum slots hold one pass, so launch and fold what is pending first — the fold accumulates
+            self.flush()
         dt = keep[0].dtype
         self._pending.setdefault(dt, []).append(problem)
         self._keep.append(keep)
         if layer_index is not None:
-            nb = nat.grad_row_blocks(problem.M)
-            if self._ran.setdefault(layer_index, nb) != nb:
-                raise RuntimeError("a LoRA layer ran backward twice with different row counts in one pass: the "
-                                   "partial-sum layout holds one pass per layer")
+            self._ran[layer_index] = nat.grad_row_blocks(problem.M)
 
     def flush(self):
         """Launch every deferred problem, then fold the partial sums of the layers that ran into `grads` (+=)."""

@@ -196,6 +196,35 @@ def test_grouped_projections_with_prior_preservation_and_hipgraph(relerr):
     assert relerr(got, e1) < 2e-3 and relerr(lg, l1) < 2e-4
 
 
+def test_two_backward_passes_before_a_flush_accumulate(relerr):
+    """Gradient accumulation over micro-batches: a layer that runs backward again before the slab was flushed must not
+    overwrite its own pending partial sums — the slab launches and folds what is pending first (the fold accumulates)."""
+    unet = _tiny64().to(DEV)
+    params, _ = dfa.inject_trainable_lora(unet, r=4)
+    _warm(list(itertools.chain(*params)))
+    set_use_memory_efficient_attention_xformers(unet, True)
+    unet.half()
+    trainer = tr.LoraTrainer(unet, lr=1e-3)
+    slab = trainer.slab
+    batches = [orc.synthetic_batch(s_, 2, 8, 6, 64) for s_ in range(2)]
+
+    def backward(i):
+        lat, noise, ts, ctx = batches[i]
+        pred = unet(lat.to(DEV).half(), ts.to(DEV), ctx.to(DEV).half()).sample
+        (pred.float() - noise.to(DEV)).pow(2).mean().backward()
+
+    grads = []
+    for which in ((0,), (1,), (0, 1)):
+        slab.zero_grad()
+        for i in which:
+            backward(i)
+        slab.flush()
+        grads.append(slab.grads[: slab.numel].clone())
+    # (an overwritten pass would show up as an error of order 1; stock f16 kernels are not bit-reproducible: a few 1e-3)
+    assert relerr(grads[2], grads[0] + grads[1]) < 1e-2, relerr(grads[2], grads[0] + grads[1])
+    assert grads[0].abs().max() > 0 and not torch.equal(grads[0], grads[1])
+
+
 def test_groups_stay_out_of_the_way_without_the_attention_hook(relerr):
     """A trainer with groups enabled on a model whose attention runs through its own forward: the groups are built but
     never entered, and the trajectory is the ungrouped trainer's (fp32; stock SDPA backward is not bit-reproducible)."""
