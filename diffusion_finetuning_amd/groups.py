@@ -52,6 +52,22 @@ class _FrozenCat:
         return self._w, self._wt
 
 
+_graph_task_id = getattr(torch._C, "_current_graph_task_id", None)
+
+
+_top_saved_hooks = getattr(torch._C._autograd, "_top_saved_tensors_default_hooks", None)
+
+
+def _in_backward() -> bool:
+    return _graph_task_id is not None and _graph_task_id() != -1
+
+
+def _saved_tensor_hooks_active() -> bool:
+    """True inside torch.utils.checkpoint(use_reentrant=False) (and save_on_cpu): what a function saves there is
+    recomputed / moved per region, so a buffer shared by several regions must not be created inside one."""
+    return _top_saved_hooks is not None and _top_saved_hooks(False) is not None
+
+
 def _same_scale(layers) -> Optional[float]:
     s = float(layers[0].scale)
     return s if all(float(l.scale) == s for l in layers) else None
@@ -229,6 +245,12 @@ class CtxKVGroup:
         self._pass = None
 
     def usable(self, ctx_t: torch.Tensor, cdtype: torch.dtype) -> bool:
+        # Not under gradient checkpointing (train_lora_dreambooth.py:627-630): it re-runs one block's forward at a time
+        # inside backward (reentrant form) or replays what a block saved (non-reentrant form), and the group's shared
+        # buffers belong to a whole forward pass, not to a block.  Those cross-attentions project their own K / V
+        # (per-module path); the reentrant form's no-grad forward and every ordinary pass use the group.
+        if _in_backward() or _saved_tensor_hooks_active():
+            return False
         return (self.A16 is not None and self.A16.dtype == cdtype and ctx_t.is_cuda and ctx_t.dim() == 3 and
                 ctx_t.shape[-1] == self.K and not ctx_t.requires_grad and _same_scale(self.layers) is not None and
                 all(not l.linear.weight.requires_grad for l in self.layers))

@@ -136,12 +136,18 @@ def _warm(params, seed=11, std=0.02):
                 p.copy_((torch.randn(p.shape, generator=g) * std).to(p.device))
 
 
-def _train(grouped, hook, steps=4, dtype=torch.float32, graph=False, prior=False, batch=2, r=4):
+def _train(grouped, hook, steps=4, dtype=torch.float32, graph=False, prior=False, batch=2, r=4, ckpt=None):
     unet = _tiny64().to(DEV).to(dtype)
     params, _ = dfa.inject_trainable_lora(unet, r=r)
     _warm(list(itertools.chain(*params)))
     if hook:
         set_use_memory_efficient_attention_xformers(unet, True)
+    if ckpt is not None:  # gradient checkpointing on every transformer block, as diffusers' enable_gradient_checkpointing does
+        from torch.utils.checkpoint import checkpoint
+
+        for m in unet.modules():
+            if type(m).__name__ == "BasicTransformerBlock":
+                m.forward = (lambda f: lambda x, ctx: checkpoint(f, x, ctx, use_reentrant=ckpt))(m.forward)
     trainer = tr.LoraTrainer(unet, lr=1e-3, group_projections=grouped, capture_graph=graph)
     losses = []
     for step in range(steps):
@@ -180,6 +186,18 @@ def test_context_group_alone_at_rank_8(relerr):
     assert not t_g.slab.qkv_groups and len(t_g.slab.ctx_groups) == 1 and t_g.slab.ctx_groups[0]._pass is not None
     _, want, lu = _train(False, True, dtype=torch.float16, r=8)
     assert relerr(lg, lu) < 2e-3 and relerr(got, want) < 2e-3, (relerr(lg, lu), relerr(got, want))
+
+
+def test_groups_under_gradient_checkpointing(relerr):
+    """train_lora_dreambooth.py:627-630 (--gradient_checkpointing) with the grouped projections switched on: the q/k/v
+    groups are per block and simply re-run; the context K/V group steps aside wherever a block's forward is replayed on
+    its own (groups.CtxKVGroup.usable), so the trajectory is the un-checkpointed one.  (Non-reentrant form: with a
+    frozen trunk the reentrant form gives no block output a grad_fn — a property of torch.utils.checkpoint, not of the
+    path under test.)"""
+    _, want, lw = _train(True, True, dtype=torch.float16)
+    tg, got, lg = _train(True, True, dtype=torch.float16, ckpt=False)
+    assert len(tg.slab.qkv_groups) == 4 and len(tg.slab.ctx_groups) == 1
+    assert relerr(lg, lw) < 2e-3 and relerr(got, want) < 2e-3, (relerr(lg, lw), relerr(got, want))
 
 
 def test_grouped_projections_with_prior_preservation_and_hipgraph(relerr):
