@@ -13,7 +13,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "lib
 _lib = None
 _lock = threading.Lock()
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 PROF_KINDS = 10
 
 _DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
