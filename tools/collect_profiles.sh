@@ -2,6 +2,7 @@
 # Collects the round's roofline evidence on the GPU box (run through gpurun from the repo root):
 #   1. rocprofv3 --kernel-trace --stats of the default bench command
 #   2-4. three SEPARATE --pmc passes (FETCH_SIZE; WRITE_SIZE; MFMA-busy counters) of a short host-launched run
+#   5. the plain default bench line (with cpu_baseline), run last so that it picks up the fresh PMC summary
 # and reduces them to the small summaries that are committed under profiles/ (tools/summarize_profile.py).
 # usage: tools/collect_profiles.sh <tag>      e.g. r02_final
 set -u
@@ -10,8 +11,6 @@ out=gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 run() { name=$1; shift; echo "[prof $name] $(date +%H:%M:%S) $*"; timeout -k 10 500 "$@" > "$out/$name.log" 2>&1; echo "[prof $name] rc=$?"; }
-run bench   python3 bench.py --steps 10 --warmup 3
-cp "$out/bench.log" "$out/bench_stdout.log"
 run trace   rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline
 run fetch   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof --no-graph
 run write   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof --no-graph
@@ -21,10 +20,13 @@ f=$(ls "$out"/pmc_fetch/*/*_counter_collection.csv | head -1)
 w=$(ls "$out"/pmc_write/*/*_counter_collection.csv | head -1)
 m=$(ls "$out"/pmc_mfma/*/*_counter_collection.csv | head -1)
 mkdir -p "$out/summary"
-grep '^{"metric"' "$out/bench.log" > "$out/summary/${tag}_bench.json"
 python3 tools/summarize_profile.py trace "$t" 4 "$out/summary/${tag}_timed_region_kernel_stats.csv" > /dev/null
 cp "$(ls "$out"/trace/*/*_kernel_stats.csv | head -1)" "$out/summary/${tag}_rocprofv3_kernel_stats_full_process.csv"
 python3 tools/summarize_profile.py pmc "$f" "$w" "$out/summary/${tag}_pmc_traffic.json" "$m" > /dev/null
+# the plain bench line LAST, with the fresh PMC summary in place, so that its roofline.traffic is this run's measurement
+cp "$out/summary/${tag}_pmc_traffic.json" profiles/
+run bench   python3 bench.py --steps 10 --warmup 3
+grep '^{"metric"' "$out/bench.log" > "$out/summary/${tag}_bench.json"
 # the raw counter CSVs are large: keep only the summaries (gpurun_out merges back <= 64 MiB)
 rm -rf "$out/trace" "$out/pmc_fetch" "$out/pmc_write" "$out/pmc_mfma"
 ls -la "$out/summary"
