@@ -69,6 +69,7 @@ SD_SHAPES = [  # (M, K, N, bias): the distinct LoRA GEMMs of SD1.5 at 512² / B=
     # long contractions on small grids (the deep-ring path); ragged row counts
     (308, 768, 768, True), (9216, 320, 320, False), (2304, 640, 640, True), (2304, 1024, 640, False),
     (576, 1280, 1280, True), (256, 1280, 1280, False), (1024, 10240, 1280, False), (333, 320, 960, False),
+    (2304, 1024, 1280, False), (77, 1024, 1280, False),
 ]
 
 
