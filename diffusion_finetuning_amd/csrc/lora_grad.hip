@@ -17,6 +17,7 @@
 // latency-bound ones.  Operands may be strided views (a slice of a grouped projection's output) and the
 // rank columns of one problem may belong to several layers (grouped q/k/v: U is [M, 3r], three gA outputs).
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -241,10 +242,13 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const int64_t* range
     }
 }
 
-// Row blocks and strips of one problem.  ~256 rows per block (at most 64 blocks): a block is then 80 KB … 1 MB of S,
-// a step's ~300 problems give several thousand workgroups, and the fold reads ≤ 64 partials per output.
+// Row blocks and strips of one problem, from a sweep over all 288 problems of an SD1.5 step (tools/gemm_bench.py --grads,
+// profiles/README.md): 512 rows per block (at most 64 blocks) and strips of 32 chunks (256 columns in 16-bit types) —
+// many narrow workgroups balance the chip better than few wide ones (541 µs at 256 rows × 256 chunks, 397 µs here, 5.0 TB/s)
+// and halve the partial sums the fold has to read.
 int plan_row_blocks(int64_t M) {
-    int64_t nb = M / 256;
+    static const int rows = [] { const char* e = getenv("LORA_GRAD_ROWS"); return e ? atoi(e) : 512; }();  // tuning knob
+    int64_t nb = M / rows;
     if (nb < 1) nb = 1;
     if (nb > LORA_GRAD_MAX_BLOCKS) nb = LORA_GRAD_MAX_BLOCKS;
     return (int)nb;
@@ -255,7 +259,7 @@ bool plan_item(GradItem& q, int nb) {
     constexpr int VEC = ElemTraits<T>::kVec;
     if (q.C % VEC != 0 || !aligned16(q.S) || (q.s_stride % VEC) != 0) return false;
     const int chunks = q.C / VEC;
-    const int cl_cap = 256;  // a strip is at most one workgroup wide
+    static const int cl_cap = [] { const char* e = getenv("LORA_GRAD_STRIP"); return e ? atoi(e) : 32; }();  // tuning knob, <= 256
     q.strips = (chunks + cl_cap - 1) / cl_cap;  // smallest strip count that respects the cap, then even widths
     q.CL = (chunks + q.strips - 1) / q.strips;
     q.nb = nb;

@@ -254,8 +254,9 @@ def test_merge_of_a_cpu_resident_model_like_lora_add_upl(golden_merge):
 def test_lerp_lora_lists_is_lora_add_lpl():
     """`lerp_lora_lists` = the LoRA ⊕ LoRA interpolation of cli_lora_add.py:44-60, op-by-op in the tensors' dtype
     (fp16 lists as `save_lora_weight` writes them).  fp32: bit-identical to the reference's torch expression on the CPU.
-    fp16: within one ulp — torch's own CPU half arithmetic is not the same on every host (the build container's CPU
-    agrees bit for bit with float-product-then-round, the GPU box's differs from it in 2 % of the elements by one ulp)."""
+    fp16: within one ulp OF THE LARGEST TERM — torch's own CPU half arithmetic is not the same on every host (the build
+    container's CPU agrees bit for bit with float-product-then-round, the GPU box's differs from it in 2 % of the elements
+    by one rounding of a product, which is more than an ulp of the SUM where the two terms cancel)."""
     g = torch.Generator().manual_seed(12)
     shapes = [(320, 4), (4, 320), (640, 4), (4, 768), (1280, 1), (1, 1280)]
     for dtype in (torch.float16, torch.float32):
@@ -263,15 +264,16 @@ def test_lerp_lora_lists_is_lora_add_lpl():
             l1 = [(torch.randn(s, generator=g) * 0.1).to(dtype) for s in shapes]
             l2 = [(torch.randn(s, generator=g) * 0.1).to(dtype) for s in shapes]
             want = [alpha * a + (1 - alpha) * b for a, b in zip(l1, l2)]  # the reference's expression, CPU torch
+            big = [torch.maximum((alpha * a.float()).abs(), ((1 - alpha) * b.float()).abs()) for a, b in zip(l1, l2)]
             keep = list(l1)
             out = dfa.lerp_lora_lists(l1, l2, alpha)
             assert len(out) == len(shapes) and all(o is k for o, k in zip(out, keep))  # merged IN PLACE (x1.data = ...)
-            for o, w in zip(out, want):
+            for o, w, t in zip(out, want, big):
                 assert o.device.type == "cpu" and o.dtype == dtype
                 if dtype == torch.float32:
                     assert torch.equal(o, w)
                 else:
-                    ulp = torch.maximum(w.float().abs(), torch.tensor(6.1e-5)) * 2.0 ** -10  # >= one half-precision ulp
+                    ulp = torch.maximum(torch.maximum(w.float().abs(), t), torch.tensor(6.1e-5)) * 2.0 ** -10  # >= one half ulp
                     assert ((o.float() - w.float()).abs() <= ulp).all()
                     assert (o == w).float().mean().item() > 0.9
     assert dfa.lerp_lora_lists([], [], 0.5) == []
