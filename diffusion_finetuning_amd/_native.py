@@ -13,7 +13,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "lib
 _lib = None
 _lock = threading.Lock()
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 PROF_KINDS = 10
 
 _DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
@@ -50,6 +50,7 @@ SIGNATURES = {
     "lora_pack_factors": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "lora_pack_factors_batched": (_i32, [_vp, _i32, _i32, _vp, _vp, _i32, _vp]),
     "lora_linear_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "lora_linear_geglu_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
     "lora_linear_bwd_input": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
     "lora_linear_bwd_params": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
     "lora_reduce_partials": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp]),
@@ -219,6 +220,23 @@ def lora_linear_fwd(x2, w, bias, a, b, scale: float, packs=None):
         "lora_linear_fwd",
     )
     return y, t
+
+
+def lora_linear_geglu_fwd(x2, w, bias, r: int, scale: float, packs, want_y: bool):
+    """`proj` forward with the GEGLU gate in the epilogue: x2 [M,K], w [2F,K], packs = (Apack, Bpack).
+    Returns (out [M,F], y [M,2F] | None, T [M,r] fp32), or None when the library has no fused kernel for the shape/dtype."""
+    _require_device(x2, w, bias)
+    M, K = x2.shape
+    N = w.shape[0]
+    out = torch.empty((M, N // 2), dtype=x2.dtype, device=x2.device)
+    y = torch.empty((M, N), dtype=x2.dtype, device=x2.device) if want_y else None
+    t = torch.empty((M, r), dtype=torch.float32, device=x2.device)
+    st = lib().lora_linear_geglu_fwd(_ptr(x2), _ptr(w), _ptr(bias), _ptr(packs[0]), _ptr(packs[1]), _ptr(y), _ptr(out),
+                                     _ptr(t), M, K, N, r, float(scale), dtype_code(x2.dtype), _stream(x2))
+    if st == -5:
+        return None
+    _check(st, "lora_linear_geglu_fwd")
+    return out, y, t
 
 
 def lora_linear_bwd_input(dy2, wt, a, b, scale: float, need_dx: bool, packs=None):

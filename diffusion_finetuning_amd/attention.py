@@ -125,7 +125,16 @@ def _hip_geglu_forward(self, hidden_states, *args, **kwargs):
         return self.__dict__[_ORIG](hidden_states, *args, **kwargs)
     from .sandwich import geglu_gate
 
-    return geglu_gate(self.proj(hidden_states))
+    proj = self.proj
+    from .core import LoraInjectedLinear
+
+    plain = (type(proj) is LoraInjectedLinear and "forward" not in proj.__dict__ and not proj._forward_hooks
+             and not proj._forward_pre_hooks)
+    if plain:
+        from .ops import lora_linear_geglu
+
+        return lora_linear_geglu(proj, hidden_states)  # the gate rides in the LoRA GEMM's epilogue: one launch
+    return geglu_gate(proj(hidden_states))
 
 
 def set_use_hip_geglu(module: nn.Module, valid: bool = True) -> int:

@@ -40,6 +40,40 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// GEGLU gate arithmetic of diffusers GEGLU.forward (exact-erf gelu), shared by sandwich.hip and the GATE epilogue of
+// lora_gemm.hip.  fp32 tensors: erff / expf.  16-bit tensors: Φ(g) from the Abramowitz–Stegun 7.1.26 form
+//     erfc(z) = t·(a1 + t·(a2 + t·(a3 + t·(a4 + t·a5))))·exp(−z²),  t = 1/(1 + p·z),  z = |g|/√2        (|ε| ≤ 1.5e-7)
+// used on the erfc side for g < 0 (no cancellation), one v_rcp_f32 + one v_exp_f32 + 8 VALU instead of erff's ~55: its error
+// is 3e-4 of a half-precision ulp for g > 0 and stays under a tenth of an ulp down to g = −3 (below that |gelu| < 4e-3·|g|),
+// and exp(−g²/2) comes out of the same evaluation for the derivative.  The erff form cost 31 µs per 16384×1280 gate tile
+// pass inside the GEMM epilogue (VALU-bound there), this one 12.
+__device__ __forceinline__ void gelu_parts_fast(float g, float& Phi, float& e) {
+    const float z = fabsf(g) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+    e = __expf(-z * z);
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float half = 0.5f * poly * e;  // Φ(−|g|)
+    Phi = g < 0.f ? half : 1.f - half;
+}
+template <typename T> __device__ __forceinline__ float gelu_f(float g) {
+    if constexpr (sizeof(T) == 4) {
+        return 0.5f * g * (1.f + erff(g * 0.70710678118654752440f));
+    } else {
+        float Phi, e;
+        gelu_parts_fast(g, Phi, e);
+        return g * Phi;
+    }
+}
+template <typename T> __device__ __forceinline__ float gelu_grad_f(float g) {  // Φ(g) + g·φ(g)
+    if constexpr (sizeof(T) == 4) {
+        return 0.5f * (1.f + erff(g * 0.70710678118654752440f)) + g * 0.39894228040143267794f * expf(-0.5f * g * g);
+    } else {
+        float Phi, e;
+        gelu_parts_fast(g, Phi, e);
+        return fmaf(g * 0.39894228040143267794f, e, Phi);
+    }
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // Zeroes the 16-byte ticket header of a reduction workspace with a KERNEL, not hipMemsetAsync: inside a captured

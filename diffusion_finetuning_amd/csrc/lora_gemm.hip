@@ -62,6 +62,11 @@ struct GemmParams {
     int splitk, steps_per_slice;
     float* ws_c;
     float* ws_p;
+    // GEGLU gate in the epilogue (GATE kernels; diffusers GEGLU.forward behind the `proj` LoraInjectedLinear): Nc = 2·gateF,
+    // a column tile owns BN/2 columns of h = C[:, :gateF] AND the matching BN/2 columns of g = C[:, gateF:], and the
+    // epilogue writes C2[M, gateF] = h·gelu(g) next to C (C may be null: nothing is saved for a backward pass).
+    void* C2;
+    int gateF;
 };
 
 constexpr int kRowBytes = 128;  // one K-step of one tile row
@@ -125,7 +130,7 @@ template <int BM, int BN, typename T, bool MAIN, int STG, int NW, int WM> conste
 
 // STG: LDS ring depth of the DMA pipeline (2 or 3); 0 selects the register-staged fallback loop.
 // NW waves as WM row waves × NW/WM column waves; every wave owns a (BM/WM) × (BN·WM/NW) piece of the tile.
-template <typename T, int BM, int BN, bool MAIN, int STG, int NW, int WM>
+template <typename T, int BM, int BN, bool MAIN, int STG, int NW, int WM, bool GATE = false>
 __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
     constexpr bool PIPE = STG > 0;
     constexpr int kStages = PIPE ? STG : 1;
@@ -194,6 +199,12 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
     STAMP(12);
     const int64_t m0 = (int64_t)tm * BM;
     const int n0 = tn * BN;
+    // tile-local column → column of C / row of Bm.  GATE: the first half of the tile is a run of h columns, the second
+    // half the run of g columns that gates them (both halves are whole: gateF % (BN/2) == 0).
+    auto gcol = [&](int c) {
+        if constexpr (GATE) return c < BN / 2 ? tn * (BN / 2) + c : p.gateF + tn * (BN / 2) + (c - BN / 2);
+        else return n0 + c;
+    };
 
     const T* Ag = static_cast<const T*>(p.Am);
     const T* Bg = static_cast<const T*>(p.Bm);
@@ -234,7 +245,7 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
     if constexpr (MAIN) {
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-            int n = n0 + ld_row + RPP * i;
+            int n = gcol(ld_row + RPP * i);
             if (n > p.Nc - 1) n = p.Nc - 1;
             b_ptr[i] = Bg + (int64_t)n * Kc;
         }
@@ -250,13 +261,13 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
             for (int base = wave * 64; base < BN * CPRQ; base += NT) {
                 const int idx = base + lane;
                 const int n = idx / CPRQ, ch = idx - n * CPRQ;
-                const int nn = n0 + n < p.Nc ? n0 + n : p.Nc - 1;
+                const int nn = gcol(n) < p.Nc ? gcol(n) : p.Nc - 1;
                 glds16(Qg + (int64_t)nn * kRP + ch * VEC, sQ + base * 16);
             }
         } else {
             for (int idx = tid; idx < BN * CPRQ; idx += NT) {
                 const int n = idx / CPRQ, ch = idx - n * CPRQ;
-                const int nn = n0 + n < p.Nc ? n0 + n : p.Nc - 1;
+                const int nn = gcol(n) < p.Nc ? gcol(n) : p.Nc - 1;
                 *reinterpret_cast<Chunk<T>*>(sQ + idx * 16) =
                     *reinterpret_cast<const Chunk<T>*>(Qg + (int64_t)nn * kRP + ch * VEC);
             }
@@ -271,7 +282,7 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
             const T* bias = static_cast<const T*>(p.bias);
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-                int col = n0 + wn * WTN + ni * 16 + lq * 4;
+                int col = gcol(wn * WTN + ni * 16 + lq * 4);
                 if (col > p.Nc - 4) col = p.Nc - 4;  // Nc % VEC == 0 here: a group of 4 is inside or past the edge
                 const Quad<T> q = *reinterpret_cast<const Quad<T>*>(bias + col);
 #pragma unroll
@@ -633,6 +644,47 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
             }
             __syncthreads();
             STAMP(7);
+            if constexpr (GATE) {
+                // thread = (row, 16-B chunk of the h half) and the chunk of g behind it: y leaves as it is (when a backward
+                // pass will want it), out = h·gelu(g) from the SAME rounded values the separate gate kernel would read
+                static_assert(FASTC && EP == 1, "the gate epilogue reads the whole C tile from one ring buffer");
+                constexpr int HC = CPR / 2;         // chunks per half row
+                constexpr int NG = ROWS * HC / NT;  // (row, chunk) pairs per thread
+                T* Og = static_cast<T*>(p.C2);
+                const int F = p.gateF;
+                Chunk<T> hv[NG], gv[NG];
+#pragma unroll
+                for (int i = 0; i < NG; ++i) {
+                    const int idx = tid + i * NT;
+                    const int row = idx / HC, ch = idx - row * HC;
+                    hv[i] = *reinterpret_cast<const Chunk<T>*>(sC + row * SC_STRIDE + ch * 16);
+                    gv[i] = *reinterpret_cast<const Chunk<T>*>(sC + row * SC_STRIDE + (HC + ch) * 16);
+                }
+                if (Cg != nullptr) {
+#pragma unroll
+                    for (int i = 0; i < NG; ++i) {
+                        const int idx = tid + i * NT;
+                        const int row = idx / HC, ch = idx - row * HC;
+                        const int64_t m = m0 + row;
+                        const int col = tn * (BN / 2) + ch * VEC;
+                        if (m < p.M) {
+                            *reinterpret_cast<Chunk<T>*>(Cg + m * p.Nc + col) = hv[i];
+                            *reinterpret_cast<Chunk<T>*>(Cg + m * p.Nc + F + col) = gv[i];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NG; ++i) {
+                    const int idx = tid + i * NT;
+                    const int row = idx / HC, ch = idx - row * HC;
+                    const int64_t m = m0 + row;
+                    Chunk<T> o;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) o.v[e] = from_f32<T>(to_f32<T>(hv[i].v[e]) * gelu_f<T>(to_f32<T>(gv[i].v[e])));
+                    if (m < p.M) *reinterpret_cast<Chunk<T>*>(Og + m * F + tn * (BN / 2) + ch * VEC) = o;
+                }
+                continue;
+            }
             constexpr int NST = ROWS * CPR / NT;  // 16-B chunks per thread
             static_assert(ROWS * CPR % NT == 0, "tile rows must split evenly over the threads");
             Chunk<T> out[NST];
@@ -913,6 +965,23 @@ int launch_tile(GemmParams p, hipStream_t stream) {
     return LORA_OK;
 }
 
+// GEGLU-gated forward: always the 128×128 two-stage ring kernel (a tile = 64 h columns + their 64 g columns).
+template <typename T>
+int launch_gate(GemmParams p, hipStream_t stream) {
+    constexpr int BM = 128, BN = 128;
+    p.tiles_m = (int)((p.M + BM - 1) / BM);
+    p.tiles_n = p.gateF / (BN / 2);
+    p.col_major = (int64_t)p.Nc > p.M ? 1 : 0;
+    constexpr int lds = gemm_lds_bytes<BM, BN, T, true, 2, 4, 2>();
+    auto kern = lora_gemm_kernel<T, BM, BN, true, 2, 4, 2, true>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (attr != hipSuccess) return LORA_E_LAUNCH;
+    LORA_LAUNCH(PK_GEMM_128x128, kern, dim3(p.tiles_m * p.tiles_n), dim3(256), lds, stream, p);
+    LORA_LAUNCH_CHECK();
+    return LORA_OK;
+}
+
 int forced_tile() {  // tuning knob for tools/gemm_bench.py only
     static const int forced = [] {
         const char* e = getenv("LORA_FORCE_TILE");
@@ -1170,6 +1239,35 @@ extern "C" int lora_linear_fwd(const void* X, const void* W, const void* bias, c
     ProfWork work(e * ((double)M * K + (double)N * K + (double)M * N) + e * r * (K + N) + (bias ? e * N : 0.0),
                   2.0 * M * K * N + 2.0 * M * r * (double)(K + N));
     return launch_gemm(c, true, dtype, s);
+}
+
+extern "C" int lora_linear_geglu_fwd(const void* X, const void* W, const void* bias, const void* Apack, const void* Bpack,
+                                     void* Y, void* Out, float* T_out, int64_t M, int K, int N, int r, float scale,
+                                     int dtype, void* stream) {
+    const int st = check_common(M, K, N, r, dtype);
+    if (st != LORA_OK) return st;
+    if ((N & 1) != 0) return LORA_E_BADARG;
+    if (M == 0) return LORA_OK;
+    if (!X || !W || !Out || !T_out) return LORA_E_BADARG;
+    // the fused epilogue exists on the LDS-DMA ring kernel for 16-bit types only; everything else: LORA_E_UNSUPPORTED, and
+    // the caller runs lora_linear_fwd + geglu_gate_fwd
+    const int F = N / 2;
+    if (dtype == LORA_F32 || r > kRP || !Apack || !Bpack || (K % 64) != 0 || (F % 64) != 0) return LORA_E_UNSUPPORTED;
+    if (!aligned16(X) || !aligned16(W) || !aligned16(Apack) || !aligned16(Bpack) || !aligned16(Out) || (Y && !aligned16(Y)) ||
+        (bias && (reinterpret_cast<uintptr_t>(bias) & 7u)))
+        return LORA_E_UNSUPPORTED;
+    GemmParams p{};
+    p.Am = X; p.Bm = W; p.bias = bias;
+    p.Fp = Apack;                                                   // A16 [16,K]
+    p.Qp = static_cast<const char*>(Bpack) + (size_t)kRP * N * 2;   // B16 [N,16]
+    p.C = Y; p.C2 = Out; p.gateF = F; p.P = T_out;
+    p.M = M; p.Kc = K; p.Nc = N; p.r = r; p.scale = scale; p.lda = K;
+    const double e = 2.0;
+    ProfWork work(e * ((double)M * K + (double)N * K + (Y ? (double)M * N : 0.0) + (double)M * F) + e * r * (K + N) +
+                      (bias ? e * N : 0.0),
+                  2.0 * M * K * N + 2.0 * M * r * (double)(K + N));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dtype == LORA_F16 ? launch_gate<half_t>(p, s) : launch_gate<bf16_t>(p, s);
 }
 
 extern "C" int64_t lora_gemm_workspace_bytes(int64_t M, int Kc, int Nc, int dtype) {

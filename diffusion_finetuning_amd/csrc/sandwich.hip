@@ -11,11 +11,6 @@
 
 namespace {
 
-__device__ __forceinline__ float gelu_f(float g) { return 0.5f * g * (1.f + erff(g * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_grad_f(float g) {
-    return 0.5f * (1.f + erff(g * 0.70710678118654752440f)) + g * 0.39894228040143267794f * expf(-0.5f * g * g);
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void geglu_fwd_kernel(const T* y, T* out, int64_t M, int C) {
     constexpr int VEC = ElemTraits<T>::kVec;
@@ -28,7 +23,7 @@ __global__ __launch_bounds__(256) void geglu_fwd_kernel(const T* y, T* out, int6
         const Chunk<T> g = *reinterpret_cast<const Chunk<T>*>(y + m * 2 * C + C + c);
         Chunk<T> o;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) o.v[e] = from_f32<T>(to_f32<T>(h.v[e]) * gelu_f(to_f32<T>(g.v[e])));
+        for (int e = 0; e < VEC; ++e) o.v[e] = from_f32<T>(to_f32<T>(h.v[e]) * gelu_f<T>(to_f32<T>(g.v[e])));
         *reinterpret_cast<Chunk<T>*>(out + m * C + c) = o;
     }
 }
@@ -48,8 +43,8 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const T* y, const T* dou
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             const float gv = to_f32<T>(g.v[e]), dv = to_f32<T>(d.v[e]);
-            dh.v[e] = from_f32<T>(dv * gelu_f(gv));
-            dg.v[e] = from_f32<T>(dv * to_f32<T>(h.v[e]) * gelu_grad_f(gv));
+            dh.v[e] = from_f32<T>(dv * gelu_f<T>(gv));
+            dg.v[e] = from_f32<T>(dv * to_f32<T>(h.v[e]) * gelu_grad_f<T>(gv));
         }
         *reinterpret_cast<Chunk<T>*>(dy + m * 2 * C + c) = dh;
         *reinterpret_cast<Chunk<T>*>(dy + m * 2 * C + C + c) = dg;

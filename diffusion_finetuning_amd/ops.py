@@ -97,41 +97,94 @@ class _LoraLinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x2, a, b, t = ctx.saved_tensors
         N = b.shape[0]
-        need_dx = ctx.needs_input_grad[0]
-        need_factors = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         dy2 = dy.reshape(-1, N)
         if dy2.dtype != x2.dtype:
             dy2 = dy2.to(x2.dtype)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        if need_dx and ctx.wt is None:
-            raise RuntimeError("lora_linear backward: Wᵀ operand was not prepared in forward")
-        dx2, u = nat.lora_linear_bwd_input(dy2, ctx.wt if need_dx else None, a, b, ctx.scale, need_dx, ctx.packs)
-        g_down = g_up = None
-        if need_factors:
-            sink = ctx.grad_sink
-            if sink is not None:
-                # trainer mode: nothing is launched here — the two reductions join the slab's batched gradient launch
-                # after backward, their row-block partials land in the model-wide partial slab (= the RCCL buffer's twin)
-                sink.defer_layer(dy2, x2, t, u, ctx.scale)
-            else:
-                g_down = torch.zeros_like(a)
-                g_up = torch.zeros_like(b)
-                nat.lora_linear_bwd_params(dy2, x2, t, u, g_down, g_up, ctx.scale)
-                if ctx.factor_dtypes[0] != torch.float32:
-                    g_down = g_down.to(ctx.factor_dtypes[0])
-                if ctx.factor_dtypes[1] != torch.float32:
-                    g_up = g_up.to(ctx.factor_dtypes[1])
-        dx = None
-        if need_dx:
-            dx = dx2.view(ctx.x_shape)
-            if dx.dtype != ctx.x_dtype:
-                dx = dx.to(ctx.x_dtype)
-        return dx, g_down, g_up, None, None, None, None, None, None
+        return (*_lora_backward(ctx, x2, a, b, t, dy2), None, None, None, None, None, None)
 
 
-def lora_linear(module, x: torch.Tensor) -> torch.Tensor:
-    """Fused LoraInjectedLinear forward (lora_diffusion/lora.py:49-50) on the HIP device."""
+def _lora_backward(ctx, x2, a, b, t, dy2):
+    """dX (one fused kernel) and the two factor gradients (deferred to the slab's batched launch in trainer mode) for
+    dy2 [M,N]; shared by the plain and the GEGLU-gated autograd fronts."""
+    need_dx = ctx.needs_input_grad[0]
+    need_factors = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+    if need_dx and ctx.wt is None:
+        raise RuntimeError("lora_linear backward: Wᵀ operand was not prepared in forward")
+    dx2, u = nat.lora_linear_bwd_input(dy2, ctx.wt if need_dx else None, a, b, ctx.scale, need_dx, ctx.packs)
+    g_down = g_up = None
+    if need_factors:
+        sink = ctx.grad_sink
+        if sink is not None:
+            # trainer mode: nothing is launched here — the two reductions join the slab's batched gradient launch
+            # after backward, their row-block partials land in the model-wide partial slab (= the RCCL buffer's twin)
+            sink.defer_layer(dy2, x2, t, u, ctx.scale)
+        else:
+            g_down = torch.zeros_like(a)
+            g_up = torch.zeros_like(b)
+            nat.lora_linear_bwd_params(dy2, x2, t, u, g_down, g_up, ctx.scale)
+            if ctx.factor_dtypes[0] != torch.float32:
+                g_down = g_down.to(ctx.factor_dtypes[0])
+            if ctx.factor_dtypes[1] != torch.float32:
+                g_up = g_up.to(ctx.factor_dtypes[1])
+    dx = None
+    if need_dx:
+        dx = dx2.view(ctx.x_shape)
+        if dx.dtype != ctx.x_dtype:
+            dx = dx.to(ctx.x_dtype)
+    return dx, g_down, g_up
+
+
+class _LoraGegluFn(torch.autograd.Function):
+    """out = h·gelu(g), [h | g] = x·Wᵀ + b + s·(x·Aᵀ)·Bᵀ — the `proj` LoraInjectedLinear of a GEGLU module together with the
+    gate of diffusers GEGLU.forward, forward in ONE launch (the gate sits in the GEMM epilogue).  y = [h | g] is written only
+    when a backward pass will need it; backward = gate backward (one streaming kernel) + the LoRA backward."""
+
+    @staticmethod
+    def forward(ctx, x, down, up, w, wt, bias, scale, grad_sink, packed):
+        K = w.shape[1]
+        x2 = x.reshape(-1, K)
+        if x2.dtype != w.dtype:
+            x2 = x2.to(w.dtype)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        a = _as_f32(down)
+        b = _as_f32(up)
+        packs = packed if packed is not None else nat.lora_pack_factors(a, b, w.dtype)
+        need = any(ctx.needs_input_grad[:3])
+        res = nat.lora_linear_geglu_fwd(x2, w, bias, a.shape[0], scale, packs, need)
+        if res is None:  # no fused kernel for this shape / dtype: the two launches it stands for
+            y2, t = nat.lora_linear_fwd(x2, w, bias, a, b, scale, packs)
+            out = nat.geglu_gate_fwd(y2)
+        else:
+            out, y2, t = res
+        if need:
+            ctx.save_for_backward(x2, a, b, t, y2)
+        ctx.packs = packs
+        ctx.wt = wt
+        ctx.scale = float(scale)
+        ctx.x_shape = x.shape
+        ctx.x_dtype = x.dtype
+        ctx.factor_dtypes = (down.dtype, up.dtype)
+        ctx.grad_sink = grad_sink
+        return out.view(*x.shape[:-1], w.shape[0] // 2)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        x2, a, b, t, y2 = ctx.saved_tensors
+        d2 = dout.reshape(-1, dout.shape[-1])
+        if d2.dtype != y2.dtype:
+            d2 = d2.to(y2.dtype)
+        if not d2.is_contiguous():
+            d2 = d2.contiguous()
+        dy2 = nat.geglu_gate_bwd(y2, d2)
+        return (*_lora_backward(ctx, x2, a, b, t, dy2), None, None, None, None, None, None)
+
+
+def lora_linear(module, x: torch.Tensor, gate: bool = False) -> torch.Tensor:
+    """Fused LoraInjectedLinear forward (lora_diffusion/lora.py:49-50) on the HIP device; `gate`: see lora_linear_geglu."""
     global _warned_trainable_base
     lin, down, up = module.linear, module.lora_down.weight, module.lora_up.weight
     if not x.is_cuda or not lin.weight.is_cuda:
@@ -153,7 +206,14 @@ def lora_linear(module, x: torch.Tensor) -> torch.Tensor:
     packed = module.__dict__.get("_dfa_packed")
     if packed is not None and packed[0].dtype != cdtype:
         packed = None
-    return _LoraLinearFn.apply(x, down, up, w, wt, bias, float(module.scale), sink, packed)
+    fn = _LoraGegluFn if gate else _LoraLinearFn
+    return fn.apply(x, down, up, w, wt, bias, float(module.scale), sink, packed)
+
+
+def lora_linear_geglu(module, x: torch.Tensor) -> torch.Tensor:
+    """`hidden * gelu(gate)` of `module(x).chunk(2, -1)` for the `proj` LoraInjectedLinear of a GEGLU block (diffusers
+    GEGLU.forward; LoRA target class "GEGLU", lora_diffusion/lora.py:53) with the gate inside the forward kernel's epilogue."""
+    return lora_linear(module, x, gate=True)
 
 
 class _DDPMLossFn(torch.autograd.Function):

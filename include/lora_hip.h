@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LORA_HIP_ABI_VERSION 2
+#define LORA_HIP_ABI_VERSION 3
 
 enum lora_dtype { LORA_F32 = 0, LORA_F16 = 1, LORA_BF16 = 2 };
 
@@ -85,6 +85,21 @@ int lora_linear_fwd(const void* X, const void* W, const void* bias /* nullable *
                     const float* A, const float* B, const void* Apack, const void* Bpack, void* Y,
                     float* T_out, int64_t M, int K, int N, int r, float scale, int dtype,
                     void* stream);
+
+/*
+ * The same forward with the GEGLU gate of its caller folded into the epilogue — diffusers GEGLU.forward
+ *     hidden, gate = proj(x).chunk(2, dim=-1);  return hidden * gelu(gate)
+ * where `proj` is a LoraInjectedLinear (target class "GEGLU", lora_diffusion/lora.py:53):
+ *     Y = X·Wᵀ + b + s·((X·Aᵀ)·Bᵀ)  [M,N],   Out = Y[:, :N/2] · gelu(Y[:, N/2:])  [M,N/2]   (exact gelu, fp32 math on the
+ *     values of Y rounded to `dtype`, exactly what geglu_gate_fwd computes from a stored Y)
+ * in ONE launch: a column tile owns 64 hidden columns and the 64 gate columns behind them.  Y may be NULL (inference /
+ * the no-grad pass of gradient checkpointing): then the [M,N] activation is never written.  16-bit dtypes, packed factors,
+ * K % 64 == 0 and N % 128 == 0 only — anything else returns LORA_E_UNSUPPORTED and the caller runs lora_linear_fwd followed
+ * by geglu_gate_fwd.
+ */
+int lora_linear_geglu_fwd(const void* X, const void* W, const void* bias /* nullable */, const void* Apack,
+                          const void* Bpack, void* Y /* nullable */, void* Out, float* T_out, int64_t M, int K, int N,
+                          int r, float scale, int dtype, void* stream);
 
 /*
  * Backward w.r.t. the input — autograd of lora.py:49-50 as driven by

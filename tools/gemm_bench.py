@@ -95,6 +95,26 @@ def grads():
     for _ in range(20): nat.lora_fold_partials(table,len(ranges),max(r_[1] for r_ in ranges),partials,stride,grads_,True)
     e1.record(); torch.cuda.synchronize()
     print(f"batched grads: {len(probs)} problems, {nl:.0f} launches, {tg:8.1f} us per step ({nbytes/tg/1e3:6.0f} GB/s algorithmic) | fold {e0.elapsed_time(e1)/20*1e3:6.1f} us (host-timed)", flush=True)
+def geglu():
+    """`proj` forward with the gate in the epilogue vs GEMM + gate kernel (host-timed pairs, graph-free)."""
+    dtype = torch.float16
+    for (M,K,F) in [(16384,320,1280),(4096,640,2560),(1024,1280,5120),(256,1280,5120)]:
+        x = torch.randn(M,K,device=dev).to(dtype); w = (torch.randn(2*F,K,device=dev)/K**0.5).to(dtype); b = torch.randn(2*F,device=dev).to(dtype)
+        a = torch.randn(4,K,device=dev)/4; up = torch.randn(2*F,4,device=dev)*0.05
+        packs = nat.lora_pack_factors(a, up, dtype)
+        def timed(fn, n=50):
+            for _ in range(5): fn()
+            e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(); e0.record()
+            for _ in range(n): fn()
+            e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1)/n*1e3
+        def two():
+            y,_ = nat.lora_linear_fwd(x,w,b,a,up,1.0,packs); nat.geglu_gate_fwd(y)
+        t_gemm, _, _ = run(lambda: nat.lora_linear_fwd(x,w,b,a,up,1.0,packs))
+        t_f, _, _ = run(lambda: nat.lora_linear_geglu_fwd(x,w,b,4,1.0,packs,True))
+        t_fn, _, _ = run(lambda: nat.lora_linear_geglu_fwd(x,w,b,4,1.0,packs,False))
+        print(f"proj {M:6d}x{K:5d}x2*{F:5d}: GEMM {t_gemm:6.1f}us | gated (y kept) {t_f:6.1f}us | gated (no y) {t_fn:6.1f}us || host-timed: two launches {timed(two):6.1f}us, fused {timed(lambda: nat.lora_linear_geglu_fwd(x,w,b,4,1.0,packs,True)):6.1f}us", flush=True)
 if "--grouped" in sys.argv: grouped()
+elif "--geglu" in sys.argv: geglu()
 elif "--grads" in sys.argv: grads()
 else: per_shape()
