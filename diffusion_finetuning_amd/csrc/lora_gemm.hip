@@ -119,7 +119,7 @@ template <int BM, int BN, bool MAIN, int STG, int NW> constexpr int stage_bytes(
 }
 template <int BM, int BN, typename T, bool MAIN, int STG, int NW, int WM> constexpr int gemm_lds_bytes() {
     constexpr int ring = (STG > 0 ? STG : 1) * stage_bytes<BM, BN, MAIN, STG, NW>();
-    constexpr int sq = MAIN ? BN * kRP * (int)sizeof(T) : 0;
+    constexpr int sq = MAIN && STG == 0 ? BN * kRP * (int)sizeof(T) : 0;  // ring kernels stage Q in a free ring buffer
     constexpr int ep = sizeof(T) == 4 ? 2 : 1;
     constexpr int sc = (MAIN && STG == 0) || (MAIN && sizeof(T) == 4) ? (BM / ep) * (BN * (int)sizeof(T) + 16) : 0;
     constexpr int sp = (NW / WM) * BM * kSPS * 4;
@@ -131,7 +131,7 @@ template <int BM, int BN, typename T, bool MAIN, int STG, int NW, int WM> conste
 // STG: LDS ring depth of the DMA pipeline (2 or 3); 0 selects the register-staged fallback loop.
 // NW waves as WM row waves × NW/WM column waves; every wave owns a (BM/WM) × (BN·WM/NW) piece of the tile.
 template <typename T, int BM, int BN, bool MAIN, int STG, int NW, int WM, bool GATE = false>
-__global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(GemmParams p) {  // 4-wave tiles: two per CU
     constexpr bool PIPE = STG > 0;
     constexpr int kStages = PIPE ? STG : 1;
     constexpr int NT = NW * 64;        // threads
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
     constexpr int OFF_F = (BM + (MAIN ? BN : 0)) * kRowBytes;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sQ = smem + kStages * STAGE;
+    char* sQ = smem + kStages * STAGE;  // (ring kernels: re-pointed into the ring when the Q tile is fetched, below)
     float* sP = reinterpret_cast<float*>(smem);  // epilogue overlay: [NW/2][BM][kSPS] (ring kernels: a free ring buffer)
 
     const int tid = threadIdx.x;
@@ -253,24 +253,26 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
     const T* f_ptr = Fg + (int64_t)(ld_row & 15) * Kc;
 
     // ---- Q tile (epilogue factor): BN packed rows of 16 values, 16-B chunks, rows clamped at the edge -----
-    if constexpr (MAIN) {
-        constexpr int CPRQ = kRP * (int)sizeof(T) / 16;  // chunks per packed row (2 for 16-bit, 4 for f32)
+    // Ring kernels fetch it by DMA during the LAST K-step into the ring buffer that is free by then (issue_q below): it
+    // costs no LDS of its own — which is what lets two 128×160 workgroups share a CU — and stays off the prologue.
+    constexpr int CPRQ = kRP * (int)sizeof(T) / 16;  // chunks per packed row (2 for 16-bit, 4 for f32)
+    constexpr int QOFF = WN * BM * kSPS * 4;         // behind the P image when both land in the same buffer
+    auto issue_q = [&](char* dst) {
         const T* Qg = static_cast<const T*>(p.Qp);
-        if constexpr (PIPE) {
-            // asynchronous: the oldest DMA of this wave, so the main loop's first counted wait covers it
-            for (int base = wave * 64; base < BN * CPRQ; base += NT) {
-                const int idx = base + lane;
-                const int n = idx / CPRQ, ch = idx - n * CPRQ;
-                const int nn = gcol(n) < p.Nc ? gcol(n) : p.Nc - 1;
-                glds16(Qg + (int64_t)nn * kRP + ch * VEC, sQ + base * 16);
-            }
-        } else {
-            for (int idx = tid; idx < BN * CPRQ; idx += NT) {
-                const int n = idx / CPRQ, ch = idx - n * CPRQ;
-                const int nn = gcol(n) < p.Nc ? gcol(n) : p.Nc - 1;
-                *reinterpret_cast<Chunk<T>*>(sQ + idx * 16) =
-                    *reinterpret_cast<const Chunk<T>*>(Qg + (int64_t)nn * kRP + ch * VEC);
-            }
+        for (int base = wave * 64; base < BN * CPRQ; base += NT) {
+            const int idx = base + lane;
+            const int n = idx / CPRQ, ch = idx - n * CPRQ;
+            const int nn = gcol(n) < p.Nc ? gcol(n) : p.Nc - 1;
+            glds16(Qg + (int64_t)nn * kRP + ch * VEC, dst + base * 16);
+        }
+    };
+    if constexpr (MAIN && !PIPE) {
+        const T* Qg = static_cast<const T*>(p.Qp);
+        for (int idx = tid; idx < BN * CPRQ; idx += NT) {
+            const int n = idx / CPRQ, ch = idx - n * CPRQ;
+            const int nn = gcol(n) < p.Nc ? gcol(n) : p.Nc - 1;
+            *reinterpret_cast<Chunk<T>*>(sQ + idx * 16) =
+                *reinterpret_cast<const Chunk<T>*>(Qg + (int64_t)nn * kRP + ch * VEC);
         }
     }
 
@@ -421,7 +423,13 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
             }
             __builtin_amdgcn_s_barrier();  // every wave's part of stage kt is in; stage kt-1 is fully read
             if (kt == 0) STAMP(3);
-            if (kt + DIST < nk) issue(kt + DIST, buf >= 1 ? buf - 1 : kStages - 1);  // refill the buffer read last step
+            char* const refill = smem + (buf >= 1 ? buf - 1 : kStages - 1) * STAGE;  // the buffer read last step
+            if (kt + DIST < nk) {
+                issue(kt + DIST, buf >= 1 ? buf - 1 : kStages - 1);
+            } else if (MAIN && kt == nk - 1 && p.splitk <= 1) {
+                sQ = refill + QOFF;  // nothing left to prefetch: the epilogue's Q tile takes the free buffer
+                issue_q(sQ);
+            }
             compute(smem + buf * STAGE, kt);
             buf = buf + 1 == kStages ? 0 : buf + 1;
         }
@@ -483,10 +491,14 @@ __global__ __launch_bounds__(NW * 64) void lora_gemm_kernel(GemmParams p) {
     // once every wave has passed the barrier below): two workgroup barriers in the whole epilogue instead of four.
     constexpr bool FREEBUF = PIPE;
     constexpr bool FASTC = PIPE && MAIN && !F32;
-    static_assert(!FREEBUF || WN * BM * kSPS * 4 <= STAGE, "P image must fit one ring buffer");
+    static_assert(!FREEBUF || QOFF + (MAIN ? BN * kRP * (int)sizeof(T) : 0) <= STAGE, "P image + Q tile must fit one ring buffer");
     char* const last_buf = smem + (buf == 0 ? kStages - 1 : buf - 1) * STAGE;
-    if constexpr (FREEBUF) sP = reinterpret_cast<float*>(smem + buf * STAGE);
-    else __syncthreads();
+    if constexpr (FREEBUF) {
+        sP = reinterpret_cast<float*>(smem + buf * STAGE);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the Q tile has landed (barrier below: everyone's)
+    } else {
+        __syncthreads();
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int row = wm * WTM + mi * 16 + l15;
@@ -1018,6 +1030,22 @@ int launch_pipe(const GemmParams& p, hipStream_t stream) {
     // (8-wave workgroups — 128×256 as 2×4 waves, 256×128 as 4×2 waves, one per CU, 26 % fewer L2→LDS bytes per flop —
     //  are supported by the template (WM parameter) and were measured: correct, 5–100 % slower on every hot-path shape,
     //  e.g. 16384×320×2560 54 vs 50 µs; not instantiated.)
+    if constexpr (sizeof(T) == 2) {
+        // widths that are whole multiples of 160 but not of 128 (320, 960: every q/k/v/out projection of the widest SD
+        // level): 128×160 tiles waste no MFMA, LDS or L2→LDS traffic on padding columns (128-wide tiles pad 320 to 384)
+        // and re-read the X panel twice instead of three times; two workgroups still share a CU (77.8 KB each)
+        const int64_t tiles160 = ((p.M + 127) / 128) * (p.Nc / 160);
+        bool w160 = (p.Nc % 160) == 0 && (p.Nc % 128) != 0 && tiles160 >= 128;
+        if (forced_tile() == 7) w160 = (p.Nc % 160) == 0;
+        if (forced_tile() == 0 || forced_tile() == 2) w160 = false;
+        if (w160) return launch_tile<T, 128, 160, true, 2, 4>(p, stream);
+        // 128×128 grids of 128..255 tiles leave a third of the CUs idle (4096×640×640: 160 tiles): 64×128 tiles double the
+        // count at 3/4 of the flops per staged byte — 12.5 → 11.0 µs there, 32.8 → 28.2 µs at K = 2560
+        bool mid = big && tiles128 < 256;
+        if (forced_tile() == 9) mid = true;
+        if (forced_tile() == 0 || forced_tile() == 2) mid = false;
+        if (mid) return launch_tile<T, 64, 128, true, 2, 4>(p, stream);
+    }
     if (big) {
         // (a 3-stage ring on grids of <= 256 tiles — one workgroup per CU anyway — was measured: no gain, 12.8 → 13.6 µs on
         //  4096×640×640; a lone workgroup is paced by the CU's vector-memory path issuing its own DMAs, not by latency)
