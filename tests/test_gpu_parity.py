@@ -1072,15 +1072,16 @@ def test_attention_hook_routes_cross_attention_through_the_hip_core(relerr):
     assert all("forward" not in m.__dict__ for m in blk.modules())
     out2, _ = run()
     assert torch.equal(out2, ref)
-    # the GEGLU switch: the feed-forward gate runs as the fused kernel and agrees with the stock chunk·gelu composite
+    # the GEGLU switch: the feed-forward gate rides in the `proj` LoRA kernel's epilogue (one launch, tests/test_gpu_geglu.py)
+    # and agrees with the stock chunk·gelu composite
     calls.clear()
-    real_gate = sandwich.geglu_gate
-    sandwich.geglu_gate = lambda *a, **kw: (calls.append(1), real_gate(*a, **kw))[1]
+    real_gate = nat.lora_linear_geglu_fwd
+    nat.lora_linear_geglu_fwd = lambda *a, **kw: (calls.append(1), real_gate(*a, **kw))[1]
     try:
         assert attention.set_use_hip_geglu(blk, True) == 1
         out3, grads3 = run()
     finally:
-        sandwich.geglu_gate = real_gate
+        nat.lora_linear_geglu_fwd = real_gate
         attention.set_use_hip_geglu(blk, False)
     assert len(calls) == 1 and relerr(out3, ref) < 2e-3
     for a, b in zip(grads3, ref_grads):
