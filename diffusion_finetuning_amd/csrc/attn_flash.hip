@@ -123,7 +123,29 @@ __device__ __forceinline__ void lds_zero(char* base, int bytes) {
 // v_exp_f32 without the library's denormal-range fix-ups (arguments here are <= 0; tiny results may flush to zero)
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-template <typename T, int KS, int DF, int RB>
+// max / sum over the four lanes that share a query row (lane = l15 + 16·lq): two row swaps on the VALU (gfx950
+// v_permlane32_swap / v_permlane16_swap) instead of two ds_bpermute round trips through the LDS crossbar
+__device__ __forceinline__ float quad_max(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const float a = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    const unsigned ua = __float_as_uint(a);
+    const auto q = __builtin_amdgcn_permlane16_swap(ua, ua, false, false);
+    return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+__device__ __forceinline__ float quad_sum(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const float a = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    const unsigned ua = __float_as_uint(a);
+    const auto q = __builtin_amdgcn_permlane16_swap(ua, ua, false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
+// ONES (head dims that leave padding rows in the Vᵀ tile, d % 16 == 8: the 40-wide heads of SD1.5's widest level): row d of
+// Vᵀ is set to ones once, so the P·V product itself accumulates Σp — on the matrix pipe, in fp32, rescaled together with
+// the output — and the 64 VALU adds and two cross-lane reductions per row block and tile disappear.
+template <typename T, int KS, int DF, int RB, bool ONES>
 __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
                                                               const T* __restrict__ V, T* __restrict__ O,
                                                               float* __restrict__ LSE, int Tq, int Tk, int H, int d,
@@ -163,6 +185,9 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restr
 
     lds_zero(smem, flash_fwd_lds_bytes<KS, DF>());
     __syncthreads();
+    if constexpr (ONES) {  // never re-staged: the stage writes rows < d only
+        if (threadIdx.x < 2 * kTile) Vt[(threadIdx.x >> 6) * S::V_HALFS + d * S::TROW + (threadIdx.x & 63)] = from_f32<T>(1.f);
+    }
     TileStage<T, KS, DF> stage;
     stage.init(d, ldq, ldq);
     stage.load(Kh, Vh, Tk);
@@ -211,25 +236,33 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restr
             for (int nf = 0; nf < kNKF; ++nf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mt = fmaxf(mt, s[rb][nf][r]);
-            mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-            const float m_new = fmaxf(m[rb], mt * scale_log2e);  // scale > 0: max commutes with the scaling
-            const float alpha = fast_exp2(m[rb] - m_new);
+            mt = quad_max(mt);
+            // Lazy rescaling: the reference maximum only moves when some row of the wave outgrows it by more than 2^8 —
+            // after the first tiles almost never — so the exp2 of the correction and the DF·4 accumulator multiplies are
+            // skipped on most tiles.  Probabilities then reach at most 2^8 (exact in fp32, far inside the 16-bit operand's
+            // range); O = o / l and LSE = m + log2 l do not depend on which m was used.
+            const float m_cand = fmaxf(m[rb], mt * scale_log2e);  // scale > 0: max commutes with the scaling
+            if (__any(m_cand > m[rb] + 8.f)) {                     // first tile: m = −inf
+                // only the rows that outgrew their reference move it (the others multiply by exp2(0) = 1): a row's result
+                // never depends on which other rows share its wave
+                const float m_upd = m_cand > m[rb] + 8.f ? m_cand : m[rb];
+                const float alpha = fast_exp2(m[rb] - m_upd);
+                m[rb] = m_upd;
+                l[rb] *= alpha;
+#pragma unroll
+                for (int df = 0; df < DF; ++df) o[rb][df] *= alpha;
+            }
+            const float m_ref = m[rb];
             float sum = 0.f;
 #pragma unroll
             for (int nf = 0; nf < kNKF; ++nf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = fast_exp2(fmaf(s[rb][nf][r], scale_log2e, -m_new));
+                    const float p = fast_exp2(fmaf(s[rb][nf][r], scale_log2e, -m_ref));
                     s[rb][nf][r] = p;
-                    sum += p;
+                    if constexpr (!ONES) sum += p;
                 }
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
-            l[rb] = l[rb] * alpha + sum;
-            m[rb] = m_new;
-#pragma unroll
-            for (int df = 0; df < DF; ++df) o[rb][df] *= alpha;
+            if constexpr (!ONES) l[rb] += quad_sum(sum);
 #pragma unroll
             for (int kk = 0; kk < kNKF / 2; ++kk) pf[rb][kk] = pair_frag<T>(s[rb][2 * kk], s[rb][2 * kk + 1]);
         }
@@ -252,6 +285,10 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restr
     for (int kt = 0; kt < n_full; ++kt) tile(kt, std::false_type{});
     if (n_full < n_tiles) tile(n_full, std::true_type{});
 
+    if constexpr (ONES) {  // Σp sits in output column d: fragment DF-1, lane group lq = 2, register 0 (d % 16 == 8)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) l[rb] = __shfl(o[rb][DF - 1][0], l15 + 32, 64);
+    }
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
         const int t = row0 + rb * 16 + l15;
@@ -666,10 +703,10 @@ struct FlashArgs {
     int64_t ldq;  // row stride (elements) shared by Q, K and V
 };
 
-template <typename T, int KS, int DF, int RB>
-int launch_flash_fwd(const FlashArgs& a, hipStream_t stream) {
+template <typename T, int KS, int DF, int RB, bool ONES>
+int launch_flash_fwd_v(const FlashArgs& a, hipStream_t stream) {
     constexpr int lds = flash_fwd_lds<KS, DF>();
-    auto kern = attn_flash_fwd_kernel<T, KS, DF, RB>;
+    auto kern = attn_flash_fwd_kernel<T, KS, DF, RB, ONES>;
     if (lds > 48 * 1024) {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -681,6 +718,13 @@ int launch_flash_fwd(const FlashArgs& a, hipStream_t stream) {
                        a.scale * 1.4426950408889634f, a.ldq);
     LORA_LAUNCH_CHECK();
     return LORA_OK;
+}
+
+template <typename T, int KS, int DF, int RB>
+int launch_flash_fwd(const FlashArgs& a, hipStream_t stream) {
+    static const int ones_env = [] { const char* e = getenv("FLASH_ONES"); return e ? atoi(e) : 1; }();  // tools/flash_check.py
+    if (ones_env && (a.d % 16) == 8 && a.d / 16 == DF - 1) return launch_flash_fwd_v<T, KS, DF, RB, true>(a, stream);
+    return launch_flash_fwd_v<T, KS, DF, RB, false>(a, stream);
 }
 
 template <typename T>

@@ -47,29 +47,31 @@ __device__ __forceinline__ float wave_sum(float v) {
 // is 3e-4 of a half-precision ulp for g > 0 and stays under a tenth of an ulp down to g = −3 (below that |gelu| < 4e-3·|g|),
 // and exp(−g²/2) comes out of the same evaluation for the derivative.  The erff form cost 31 µs per 16384×1280 gate tile
 // pass inside the GEMM epilogue (VALU-bound there), this one 12.
-__device__ __forceinline__ void gelu_parts_fast(float g, float& Phi, float& e) {
+__device__ __forceinline__ void gelu_parts_fast(float g, float& half, float& e) {  // half = Φ(−|g|), e = exp(−g²/2)
     const float z = fabsf(g) * 0.70710678118654752440f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
     e = __expf(-z * z);
-    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-    const float half = 0.5f * poly * e;  // Φ(−|g|)
-    Phi = g < 0.f ? half : 1.f - half;
+    // the A&S coefficients halved: Φ(−|g|) = erfc(z)/2
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 0.5307027145f, -0.7265760135f), 0.7107068705f), -0.142248368f), 0.127414796f);
+    half = poly * e;
 }
 template <typename T> __device__ __forceinline__ float gelu_f(float g) {
     if constexpr (sizeof(T) == 4) {
         return 0.5f * g * (1.f + erff(g * 0.70710678118654752440f));
     } else {
-        float Phi, e;
-        gelu_parts_fast(g, Phi, e);
-        return g * Phi;
+        // g·Φ(g) = max(g, 0) − |g|·Φ(−|g|) on both sides of zero: no select, no 1 − x
+        float half, e;
+        gelu_parts_fast(g, half, e);
+        return fmaf(-fabsf(g), half, fmaxf(g, 0.f));
     }
 }
 template <typename T> __device__ __forceinline__ float gelu_grad_f(float g) {  // Φ(g) + g·φ(g)
     if constexpr (sizeof(T) == 4) {
         return 0.5f * (1.f + erff(g * 0.70710678118654752440f)) + g * 0.39894228040143267794f * expf(-0.5f * g * g);
     } else {
-        float Phi, e;
-        gelu_parts_fast(g, Phi, e);
+        float half, e;
+        gelu_parts_fast(g, half, e);
+        const float Phi = g < 0.f ? half : 1.f - half;
         return fmaf(g * 0.39894228040143267794f, e, Phi);
     }
 }

@@ -538,7 +538,41 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
         }
         return;
     }
-    if (write_p) {
+    constexpr bool PACKED_P = MAIN && !F32 && PIPE;  // the rank-r term's operand is built ONCE per row, cooperatively
+    constexpr int kPkStride = 80;                     // bytes per row of the packed image [hi j0..15 | lo j0..15] (+16 pad)
+    char* const sPk = reinterpret_cast<char*>(sP) + QOFF + (MAIN ? BN * kRP * (int)sizeof(T) : 0);
+    if constexpr (PACKED_P) {
+        // thread = (row, half of the 16 rank slots): sums the wave partials, writes P out, and leaves s·P split into a
+        // high and a low 16-bit part in MFMA operand order — every wave then fetches a fragment with ONE 16-byte read
+        // instead of rebuilding it from 2·WN fp32 reads and 40 conversions per lane (4× redundantly across the workgroup)
+        static_assert(QOFF + BN * kRP * (int)sizeof(T) + BM * kPkStride <= STAGE, "P partials + Q tile + packed P fit one buffer");
+        const int half = tid & 1;
+        for (int row = tid >> 1; row < BM; row += NT / 2) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < WN; ++w) {
+                const f32x4* src = reinterpret_cast<const f32x4*>(&sP[(w * BM + row) * kSPS + half * 8]);
+                a += src[0];
+                b += src[1];
+            }
+            const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+            if (write_p && m0 + row < p.M) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (half * 8 + e < p.r) Pout[(m0 + row) * p.r + half * 8 + e] = v[e];
+            }
+            Chunk<T> hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float sv = v[e] * p.scale;
+                hi.v[e] = from_f32<T>(sv);
+                lo.v[e] = from_f32<T>(sv - to_f32<T>(hi.v[e]));
+            }
+            *reinterpret_cast<Chunk<T>*>(sPk + row * kPkStride + half * 16) = hi;
+            *reinterpret_cast<Chunk<T>*>(sPk + row * kPkStride + 32 + half * 16) = lo;
+        }
+        __syncthreads();
+    } else if (write_p) {
         const int half = tid & 1;
         for (int row = tid >> 1; row < BM && m0 + row < p.M; row += NT / 2) {
 #pragma unroll
@@ -565,6 +599,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
             for (int ni = 0; ni < NI; ++ni)
                 qf[ni] = *reinterpret_cast<const Frag*>(
                     sQ + ((wn * WTN + ni * 16 + l15) * kRP + j0) * (int)sizeof(T));
+            if constexpr (PACKED_P) {
+                Frag pf[MI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    pf[mi] = *reinterpret_cast<const Frag*>(sPk + (wm * WTM + mi * 16 + l15) * kPkStride + lq * 16);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = Mfma<T>::run(qf[ni], pf[mi], acc[mi][ni]);
+            } else {
             constexpr int MG = MI < 4 ? MI : 4;  // row fragments whose P image is fetched together
 #pragma unroll
             for (int mg = 0; mg < MI; mg += MG) {
@@ -595,6 +639,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) acc[mg + i][ni] = Mfma<T>::run(qf[ni], pf, acc[mg + i][ni]);
                 }
+            }
             }
         } else {
             const float* q = reinterpret_cast<const float*>(sQ);
@@ -1012,7 +1057,8 @@ int forced_tile() {  // tuning knob for tools/gemm_bench.py only
 //    two independent 128×128 workgroups per CU on every hot-path shape: one wave per SIMD cannot hide its own LDS and
 //    barrier latency.  Not instantiated either (the template still supports it).
 template <typename T, bool MAIN>
-int launch_pipe(const GemmParams& p, hipStream_t stream) {
+int launch_pipe(const GemmParams& p_in, hipStream_t stream) {
+    const GemmParams& p = p_in;
     if (!MAIN) return launch_tile<T, 64, 64, false, 3>(p, stream);
     static const int stg_env = [] { const char* e = getenv("LORA_FORCE_STAGES"); return e ? atoi(e) : 0; }();
     if (p.splitk > 1) return launch_tile<T, 128, 128, true, 2>(p, stream);
@@ -1037,14 +1083,19 @@ int launch_pipe(const GemmParams& p, hipStream_t stream) {
         const int64_t tiles160 = ((p.M + 127) / 128) * (p.Nc / 160);
         bool w160 = (p.Nc % 160) == 0 && (p.Nc % 128) != 0 && tiles160 >= 128;
         if (forced_tile() == 7) w160 = (p.Nc % 160) == 0;
-        if (forced_tile() == 0 || forced_tile() == 2) w160 = false;
+        if (forced_tile() == 0 || forced_tile() == 2 || forced_tile() == 1) w160 = false;  // 1: the 128|64-square rules only
         if (w160) return launch_tile<T, 128, 160, true, 2, 4>(p, stream);
         // 128×128 grids of 128..255 tiles leave a third of the CUs idle (4096×640×640: 160 tiles): 64×128 tiles double the
         // count at 3/4 of the flops per staged byte — 12.5 → 11.0 µs there, 32.8 → 28.2 µs at K = 2560
         bool mid = big && tiles128 < 256;
         if (forced_tile() == 9) mid = true;
-        if (forced_tile() == 0 || forced_tile() == 2) mid = false;
+        if (forced_tile() == 0 || forced_tile() == 2 || forced_tile() == 1) mid = false;
         if (mid) return launch_tile<T, 64, 128, true, 2, 4>(p, stream);
+        // grids too small for 128-row tiles, measured with the weights COLD (tools/gemm_bench.py --cold-read: in the model every
+        // frozen weight comes from HBM): 64×128 tiles behind a 3-stage ring (two workgroups per CU, two K-steps in flight)
+        // for 64..127-tile grids — 1024×1280×1280: 17.3 → 15.0 µs, the grouped q/k/v backward at 1024 rows 39 → 34 µs
+        if (!big && tiles128 >= 64 && (p.Nc % 128) == 0 && stg_env == 0 && forced_tile() < 0)
+            return launch_tile<T, 64, 128, true, 3, 4>(p, stream);
     }
     if (big) {
         // (a 3-stage ring on grids of <= 256 tiles — one workgroup per CU anyway — was measured: no gain, 12.8 → 13.6 µs on
@@ -1058,10 +1109,9 @@ int launch_pipe(const GemmParams& p, hipStream_t stream) {
     // of each K-step there (4 stages = 2 workgroups per CU, 6 stages = 1)
     const int nk = (p.Kc * (int)sizeof(T) + kRowBytes - 1) / kRowBytes;
     int ring = deep ? 3 : 2;
-    if (deep && nk >= 8) ring = tiles64 <= 256 ? 6 : 4;
-    if (stg_env == 4 || stg_env == 6) ring = stg_env;
+    if (deep && nk >= 8) ring = 4;  // (6 stages at one workgroup per CU lost to 4 stages at two once the weights are cold)
+    if (stg_env == 4) ring = stg_env;
     switch (ring) {
-        case 6: return launch_tile<T, 64, 64, true, 6>(p, stream);
         case 4: return launch_tile<T, 64, 64, true, 4>(p, stream);
         case 3: return launch_tile<T, 64, 64, true, 3>(p, stream);
         default: return launch_tile<T, 64, 64, true, 2>(p, stream);

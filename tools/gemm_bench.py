@@ -6,7 +6,18 @@ import torch
 from diffusion_finetuning_amd import _native as nat
 dev = "cuda"
 SHAPES = [(16384,320,320),(16384,320,2560),(16384,1280,320),(4096,640,640),(4096,640,5120),(4096,2560,640),(1024,1280,1280),(1024,1280,10240),(1024,5120,1280),(256,1280,1280),(256,1280,10240),(308,768,320),(308,768,1280)]
-def run(fn, iters=20):
+COLD = "--cold" in sys.argv or "--cold-read" in sys.argv  # in-model conditions: weights come from HBM (a 600 MB write evicts L2 + Infinity Cache), the row operand was just written
+_flush = None
+def run(fn, iters=20, warm=None):
+    global _flush
+    if COLD:
+        if _flush is None: _flush = torch.empty(600 * 1024 * 1024, dtype=torch.uint8, device=dev)
+        inner = fn
+        def fn():
+            if "--cold-read" in sys.argv: _flush.view(torch.float32).sum()  # evict with CLEAN lines (no write-backs competing with the kernel)
+            else: _flush.zero_()
+            if warm is not None: warm.mul_(1.0)
+            inner()
     for _ in range(3): fn()
     torch.cuda.synchronize()
     nat.prof_enable(16 * iters + 64)
@@ -26,8 +37,8 @@ def per_shape():
         a = torch.randn(4,K,device=dev)/4; b = torch.randn(N,4,device=dev)*0.05; dy = torch.randn(M,N,device=dev).to(dtype)
         y, t = nat.lora_linear_fwd(x,w,None,a,b,1.0); dx,u = nat.lora_linear_bwd_input(dy,wt,a,b,1.0,True)
         ga = torch.zeros(4,K,device=dev); gb = torch.zeros(N,4,device=dev)
-        tf, _, kf = run(lambda: nat.lora_linear_fwd(x,w,None,a,b,1.0))
-        tb, _, kb = run(lambda: nat.lora_linear_bwd_input(dy,wt,a,b,1.0,True))
+        tf, _, kf = run(lambda: nat.lora_linear_fwd(x,w,None,a,b,1.0), warm=x)
+        tb, _, kb = run(lambda: nat.lora_linear_bwd_input(dy,wt,a,b,1.0,True), warm=dy)
         fl = 2.0*M*K*N; by = 2.0*(M*K+N*K+M*N)
         line = f"{M:6d}x{K:5d}x{N:6d} fwd {tf:7.1f}us {fl/tf/1e6:6.0f}TF {by/tf/1e3:6.0f}GB/s [{kf[0][18:28]}] | bwd {tb:7.1f}us {fl/tb/1e6:6.0f}TF [{kb[0][18:28]}] {kb[-1] if len(kb) > 1 else ''}"
         if "--ref" in sys.argv:
@@ -50,8 +61,8 @@ def grouped():
         for g in range(G):
             blk = (torch.randn(N,r,device=dev)*0.05).to(dtype); Qb[g*N:(g+1)*N, g*r:(g+1)*r] = blk; Fb[g*r:(g+1)*r, g*N:(g+1)*N] = blk.t()
         y = torch.empty(M,G*N,device=dev,dtype=dtype); t = torch.empty(M,12,device=dev); dx = torch.empty(M,K,device=dev,dtype=dtype); u = torch.empty(M,12,device=dev)
-        tf, _, kf = run(lambda: nat.lora_gemm_packed(x,K,w,None,Fa,Qb,None,None,0,y,t,M,K,G*N,12,1.0))
-        tb, _, kb = run(lambda: nat.lora_gemm_packed(dy,G*N,wt,None,Fb,Qa,None,None,0,dx,u,M,G*N,K,12,1.0))
+        tf, _, kf = run(lambda: nat.lora_gemm_packed(x,K,w,None,Fa,Qb,None,None,0,y,t,M,K,G*N,12,1.0), warm=x)
+        tb, _, kb = run(lambda: nat.lora_gemm_packed(dy,G*N,wt,None,Fb,Qa,None,None,0,dx,u,M,G*N,K,12,1.0), warm=dy)
         by = 2.0*(M*K+G*N*K+M*G*N)
         print(f"qkv {M:6d}x{K:5d}x3*{N:5d} fwd {tf:7.1f}us {by/tf/1e3:6.0f}GB/s [{kf[0][18:28]}] | bwd {tb:7.1f}us {by/tb/1e3:6.0f}GB/s [{kb[0][18:28]}] {kb[-1] if len(kb) > 1 else ''}", flush=True)
     M, K, r = 308, 768, 4

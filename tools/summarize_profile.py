@@ -79,8 +79,28 @@ def pmc(fetch, write, out, mfma=None):
     print(json.dumps(res, indent=1))
 
 
+def shapes(path, warmup):
+    """In-model time of every hot-path launch class: dispatches of the timed region grouped by (kernel, grid, LDS)."""
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    starts = [int(r["Start_Timestamp"]) for r in rows if "add_noise_kernel" in r["Kernel_Name"]]
+    t0 = starts[warmup]
+    steps = len(starts) - warmup
+    agg = collections.defaultdict(list)
+    for r in rows:
+        if int(r["Start_Timestamp"]) >= t0 and ("lora_" in r["Kernel_Name"] or "attn_" in r["Kernel_Name"] or "geglu" in r["Kernel_Name"]):
+            name = re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", r["Kernel_Name"])[:46]
+            key = (name, int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])), int(r.get("Grid_Size_Y", 1) or 1), int(r["LDS_Block_Size"]))
+            agg[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    print(f"{'kernel':46s} {'blocks':>7s} {'gy':>4s} {'lds':>7s} {'n/step':>7s} {'avg us':>8s} {'min':>7s} {'max':>7s} {'us/step':>8s}")
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        print(f"{k[0]:46s} {k[1]:7d} {k[2]:4d} {k[3]:7d} {len(v) / steps:7.1f} {sum(v) / len(v) / 1e3:8.1f} {min(v) / 1e3:7.1f} {max(v) / 1e3:7.1f} {sum(v) / steps / 1e3:8.1f}")
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "trace":
+    if sys.argv[1] == "shapes":
+        shapes(sys.argv[2], int(sys.argv[3]))
+    elif sys.argv[1] == "trace":
         trace(sys.argv[2], int(sys.argv[3]), sys.argv[4])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else None)
