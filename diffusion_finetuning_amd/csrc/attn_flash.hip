@@ -203,78 +203,181 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restr
         const T* Vc = Vt + cur * S::V_HALFS;
         if (kt + 1 < n_tiles) stage.load(Kh + (int64_t)(kt + 1) * kTile * ldq, Vh + (int64_t)(kt + 1) * kTile * ldq, Tk - (kt + 1) * kTile);  // in flight during this tile's work
 
-        // ---- Sᵀ = K·Qᵀ: every K fragment read once, used for all RB row blocks -----------------
-        f32x4 s[RB][kNKF];
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int nf = 0; nf < kNKF; ++nf) s[rb][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int nf = 0; nf < kNKF; ++nf)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const F8 kf = *reinterpret_cast<const F8*>(Kc + (nf * 16 + l15) * S::KROW + ks * 32 + lq * 8);
-#pragma unroll
-                for (int rb = 0; rb < RB; ++rb) s[rb][nf] = Mma<T>::k32(kf, qf[rb][ks], s[rb][nf]);
-            }
-        // ---- online softmax, one query row per lane (raw scores stay unscaled: exp2(s·c − m) is one fma + v_exp) ----
-        if constexpr (RAGGED) {  // keys past Tk never win the max and get probability 0
-            const int key_base = kt * kTile + lq * 4;
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
+        // Narrow heads (the fragments of a whole tile fit the register file): software pipeline, below.  Wide heads keep the
+        // phase-by-phase form — resident fragments and the look-ahead accumulators would spill there.
+        constexpr bool RES = 4 * KS + 2 * DF <= 22 && RB * DF <= 12;
+        if constexpr (RES) {
+            // ---- software pipeline over the RB row blocks: the score MFMAs of block rb+1 are issued BEFORE the softmax of
+            // block rb, so that block's exp2 / max / convert VALU work runs while the matrix pipe chews on the next block's
+            // scores (and on this block's P·V behind them) instead of the two pipes taking turns.  The K and Vᵀ fragments of
+            // the tile are read from LDS once and stay in registers for all row blocks.
+            F8 kf[RES ? kNKF : 1][RES ? KS : 1], vf[RES ? DF : 1][RES ? kNKF / 2 : 1];
+            auto kfrag = [&](int nf, int ks) {
+                if constexpr (RES) return kf[nf][ks];
+                else return *reinterpret_cast<const F8*>(Kc + (nf * 16 + l15) * S::KROW + ks * 32 + lq * 8);
+            };
+            auto vfrag = [&](int df, int kk) {
+                if constexpr (RES) return vf[df][kk];
+                else return *reinterpret_cast<const F8*>(Vc + (df * 16 + l15) * S::TROW + kk * 32 + lq * 8);
+            };
+            if constexpr (RES) {
+    #pragma unroll
                 for (int nf = 0; nf < kNKF; ++nf)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (key_base + nf * 16 + r >= Tk) s[rb][nf][r] = -INFINITY;
-        }
-        F8 pf[RB][kNKF / 2];
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
-            float mt = -INFINITY;
-#pragma unroll
-            for (int nf = 0; nf < kNKF; ++nf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mt = fmaxf(mt, s[rb][nf][r]);
-            mt = quad_max(mt);
-            // Lazy rescaling: the reference maximum only moves when some row of the wave outgrows it by more than 2^8 —
-            // after the first tiles almost never — so the exp2 of the correction and the DF·4 accumulator multiplies are
-            // skipped on most tiles.  Probabilities then reach at most 2^8 (exact in fp32, far inside the 16-bit operand's
-            // range); O = o / l and LSE = m + log2 l do not depend on which m was used.
-            const float m_cand = fmaxf(m[rb], mt * scale_log2e);  // scale > 0: max commutes with the scaling
-            if (__any(m_cand > m[rb] + 8.f)) {                     // first tile: m = −inf
-                // only the rows that outgrew their reference move it (the others multiply by exp2(0) = 1): a row's result
-                // never depends on which other rows share its wave
-                const float m_upd = m_cand > m[rb] + 8.f ? m_cand : m[rb];
-                const float alpha = fast_exp2(m[rb] - m_upd);
-                m[rb] = m_upd;
-                l[rb] *= alpha;
-#pragma unroll
-                for (int df = 0; df < DF; ++df) o[rb][df] *= alpha;
+    #pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+                        kf[nf][ks] = *reinterpret_cast<const F8*>(Kc + (nf * 16 + l15) * S::KROW + ks * 32 + lq * 8);
+    #pragma unroll
+                for (int df = 0; df < DF; ++df)
+    #pragma unroll
+                    for (int kk = 0; kk < kNKF / 2; ++kk)
+                        vf[df][kk] = *reinterpret_cast<const F8*>(Vc + (df * 16 + l15) * S::TROW + kk * 32 + lq * 8);
             }
-            const float m_ref = m[rb];
-            float sum = 0.f;
-#pragma unroll
-            for (int nf = 0; nf < kNKF; ++nf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = fast_exp2(fmaf(s[rb][nf][r], scale_log2e, -m_ref));
-                    s[rb][nf][r] = p;
-                    if constexpr (!ONES) sum += p;
+            auto scores = [&](int rb, f32x4 (&sc)[kNKF]) {  // Sᵀ = K·Qᵀ for one 16-row block
+    #pragma unroll
+                for (int nf = 0; nf < kNKF; ++nf) {
+                    sc[nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) sc[nf] = Mma<T>::k32(kfrag(nf, ks), qf[rb][ks], sc[nf]);
                 }
-            if constexpr (!ONES) l[rb] += quad_sum(sum);
-#pragma unroll
-            for (int kk = 0; kk < kNKF / 2; ++kk) pf[rb][kk] = pair_frag<T>(s[rb][2 * kk], s[rb][2 * kk + 1]);
-        }
-        // ---- Oᵀ += Vᵀ·Pᵀ -------------------------------------------------------------------------------------
-#pragma unroll
-        for (int df = 0; df < DF; ++df)
-#pragma unroll
-            for (int kk = 0; kk < kNKF / 2; ++kk) {
-                const F8 vf = *reinterpret_cast<const F8*>(Vc + (df * 16 + l15) * S::TROW + kk * 32 + lq * 8);
-#pragma unroll
-                for (int rb = 0; rb < RB; ++rb) o[rb][df] = Mma<T>::k32(vf, pf[rb][kk], o[rb][df]);
+            };
+            f32x4 s_cur[kNKF], s_nxt[RES ? kNKF : 1];
+            if constexpr (RES) scores(0, s_cur);
+    #pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                if constexpr (RES) {
+                    if (rb + 1 < RB) scores(rb + 1, s_nxt);
+                } else {
+                    scores(rb, s_cur);  // no look-ahead where its 16 extra accumulator registers would spill
+                }
+                // ---- online softmax, one query row per lane (raw scores stay unscaled: exp2(s·c − m) is one fma + v_exp) ----
+                if constexpr (RAGGED) {  // keys past Tk never win the max and get probability 0
+                    const int key_base = kt * kTile + lq * 4;
+    #pragma unroll
+                    for (int nf = 0; nf < kNKF; ++nf)
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (key_base + nf * 16 + r >= Tk) s_cur[nf][r] = -INFINITY;
+                }
+                float mt = -INFINITY;
+    #pragma unroll
+                for (int nf = 0; nf < kNKF; ++nf)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) mt = fmaxf(mt, s_cur[nf][r]);
+                mt = quad_max(mt);
+                // Lazy rescaling: the reference maximum only moves when some row of the wave outgrows it by more than 2^8 —
+                // after the first tiles almost never — so the exp2 of the correction and the DF·4 accumulator multiplies are
+                // skipped on most tiles.  Probabilities then reach at most 2^8 (exact in fp32, far inside the 16-bit operand's
+                // range); O = o / l and LSE = m + log2 l do not depend on which m was used.
+                const float m_cand = fmaxf(m[rb], mt * scale_log2e);  // scale > 0: max commutes with the scaling
+                if (__any(m_cand > m[rb] + 8.f)) {                     // first tile: m = −inf
+                    // only the rows that outgrew their reference move it (the others multiply by exp2(0) = 1): a row's result
+                    // never depends on which other rows share its wave
+                    const float m_upd = m_cand > m[rb] + 8.f ? m_cand : m[rb];
+                    const float alpha = fast_exp2(m[rb] - m_upd);
+                    m[rb] = m_upd;
+                    l[rb] *= alpha;
+    #pragma unroll
+                    for (int df = 0; df < DF; ++df) o[rb][df] *= alpha;
+                }
+                const float m_ref = m[rb];
+                float sum = 0.f;
+    #pragma unroll
+                for (int nf = 0; nf < kNKF; ++nf)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = fast_exp2(fmaf(s_cur[nf][r], scale_log2e, -m_ref));
+                        s_cur[nf][r] = p;
+                        if constexpr (!ONES) sum += p;
+                    }
+                if constexpr (!ONES) l[rb] += quad_sum(sum);
+                // ---- Oᵀ += Vᵀ·Pᵀ for this block ----------------------------------------------------------------------
+    #pragma unroll
+                for (int kk = 0; kk < kNKF / 2; ++kk) {
+                    const F8 pf = pair_frag<T>(s_cur[2 * kk], s_cur[2 * kk + 1]);
+    #pragma unroll
+                    for (int df = 0; df < DF; ++df) o[rb][df] = Mma<T>::k32(vfrag(df, kk), pf, o[rb][df]);
+                }
+                if constexpr (RES) {
+                    if (rb + 1 < RB) {
+    #pragma unroll
+                        for (int nf = 0; nf < kNKF; ++nf) s_cur[nf] = s_nxt[nf];
+                    }
+                }
             }
+        } else {
+            // ---- Sᵀ = K·Qᵀ: every K fragment read once, used for all RB row blocks -----------------
+            f32x4 s[RB][kNKF];
+    #pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+    #pragma unroll
+                for (int nf = 0; nf < kNKF; ++nf) s[rb][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+            for (int nf = 0; nf < kNKF; ++nf)
+    #pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const F8 kf = *reinterpret_cast<const F8*>(Kc + (nf * 16 + l15) * S::KROW + ks * 32 + lq * 8);
+    #pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) s[rb][nf] = Mma<T>::k32(kf, qf[rb][ks], s[rb][nf]);
+                }
+            // ---- online softmax, one query row per lane (raw scores stay unscaled: exp2(s·c − m) is one fma + v_exp) ----
+            if constexpr (RAGGED) {  // keys past Tk never win the max and get probability 0
+                const int key_base = kt * kTile + lq * 4;
+    #pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+    #pragma unroll
+                    for (int nf = 0; nf < kNKF; ++nf)
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (key_base + nf * 16 + r >= Tk) s[rb][nf][r] = -INFINITY;
+            }
+            F8 pf[RB][kNKF / 2];
+    #pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                float mt = -INFINITY;
+    #pragma unroll
+                for (int nf = 0; nf < kNKF; ++nf)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) mt = fmaxf(mt, s[rb][nf][r]);
+                mt = quad_max(mt);
+                // Lazy rescaling: the reference maximum only moves when some row of the wave outgrows it by more than 2^8 —
+                // after the first tiles almost never — so the exp2 of the correction and the DF·4 accumulator multiplies are
+                // skipped on most tiles.  Probabilities then reach at most 2^8 (exact in fp32, far inside the 16-bit operand's
+                // range); O = o / l and LSE = m + log2 l do not depend on which m was used.
+                const float m_cand = fmaxf(m[rb], mt * scale_log2e);  // scale > 0: max commutes with the scaling
+                if (__any(m_cand > m[rb] + 8.f)) {                     // first tile: m = −inf
+                    // only the rows that outgrew their reference move it (the others multiply by exp2(0) = 1): a row's result
+                    // never depends on which other rows share its wave
+                    const float m_upd = m_cand > m[rb] + 8.f ? m_cand : m[rb];
+                    const float alpha = fast_exp2(m[rb] - m_upd);
+                    m[rb] = m_upd;
+                    l[rb] *= alpha;
+    #pragma unroll
+                    for (int df = 0; df < DF; ++df) o[rb][df] *= alpha;
+                }
+                const float m_ref = m[rb];
+                float sum = 0.f;
+    #pragma unroll
+                for (int nf = 0; nf < kNKF; ++nf)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = fast_exp2(fmaf(s[rb][nf][r], scale_log2e, -m_ref));
+                        s[rb][nf][r] = p;
+                        if constexpr (!ONES) sum += p;
+                    }
+                if constexpr (!ONES) l[rb] += quad_sum(sum);
+    #pragma unroll
+                for (int kk = 0; kk < kNKF / 2; ++kk) pf[rb][kk] = pair_frag<T>(s[rb][2 * kk], s[rb][2 * kk + 1]);
+            }
+            // ---- Oᵀ += Vᵀ·Pᵀ -------------------------------------------------------------------------------------
+    #pragma unroll
+            for (int df = 0; df < DF; ++df)
+    #pragma unroll
+                for (int kk = 0; kk < kNKF / 2; ++kk) {
+                    const F8 vf = *reinterpret_cast<const F8*>(Vc + (df * 16 + l15) * S::TROW + kk * 32 + lq * 8);
+    #pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) o[rb][df] = Mma<T>::k32(vf, pf[rb][kk], o[rb][df]);
+                }
+        }
         if (kt + 1 < n_tiles) {
             stage.store_a_rows(Ks + (cur ^ 1) * S::K_HALFS);
             stage.store_b_transposed(Vt + (cur ^ 1) * S::V_HALFS);
