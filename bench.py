@@ -148,7 +148,7 @@ def measured_traffic(kernel_name, dtype):
 
     from diffusion_finetuning_amd import build_native
 
-    m = re.search(r"<\*, (\d+), (\d+), (true|false)>", kernel_name)
+    m = re.search(r"<\*, (\d+), ([\d|]+), (true|false)>", kernel_name)  # a profiler class may cover several tile widths
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
     if not files or dtype != "f16":
         return None
@@ -158,11 +158,13 @@ def measured_traffic(kernel_name, dtype):
     if not built_from or table.get("_csrc_digest") != built_from:
         return None
     if m:
-        prefix = f"lora_gemm_kernel<DF16_,{m.group(1)},{m.group(2)},{1 if m.group(3) == 'true' else 0}"
+        prefixes = [f"lora_gemm_kernel<DF16_,{m.group(1)},{bn},{1 if m.group(3) == 'true' else 0}" for bn in m.group(2).split("|")]
     else:
-        prefix = kernel_name.split("<")[0]
-    entry = next((v for k, v in table.items() if k.startswith(prefix)), None)
-    return entry["traffic_bytes_per_launch"] if entry else None
+        prefixes = [kernel_name.split("<")[0]]
+    entries = [v for k, v in table.items() if isinstance(v, dict) and any(k.startswith(p) for p in prefixes)
+               and "traffic_bytes_per_launch" in v]
+    n = sum(e.get("dispatches", 1) for e in entries)
+    return sum(e["traffic_bytes_per_launch"] * e.get("dispatches", 1) for e in entries) / n if n else None
 
 
 def usable_cpus() -> int:

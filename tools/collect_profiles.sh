@@ -22,6 +22,7 @@ m=$(ls "$out"/pmc_mfma/*/*_counter_collection.csv | head -1)
 mkdir -p "$out/summary"
 python3 tools/summarize_profile.py trace "$t" 4 "$out/summary/${tag}_timed_region_kernel_stats.csv" > /dev/null
 cp "$(ls "$out"/trace/*/*_kernel_stats.csv | head -1)" "$out/summary/${tag}_rocprofv3_kernel_stats_full_process.csv"
+python3 tools/summarize_profile.py shapes "$t" 4 > "$out/summary/${tag}_inmodel_launch_classes.txt"
 python3 tools/summarize_profile.py pmc "$f" "$w" "$out/summary/${tag}_pmc_traffic.json" "$m" > /dev/null
 # the plain bench line LAST, with the fresh PMC summary in place, so that its roofline.traffic is this run's measurement
 cp "$out/summary/${tag}_pmc_traffic.json" profiles/
