@@ -693,13 +693,11 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
                 // transposed operands (lane = head-dim column, same contraction slots), one fragment at a time
 #pragma unroll
                 for (int df = 0; df < DF; ++df) {
-                    F8 qT, gT;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int row = r0 + (e >> 2) * 16 + lq * 4 + (e & 3);
-                        qT[e] = Qc[row * S::KROW + df * 16 + l15];
-                        gT[e] = Gc[row * S::KROW + df * 16 + l15];
-                    }
+                    // rows r0 + hb*16 + lq*4 + (0..3), column df*16 + l15: two transposing block reads per operand
+                    const F8 qT = tr_pair<T>(lds_tr_block(Qc + r0 * S::KROW + df * 16, S::KROW, lane),
+                                             lds_tr_block(Qc + (r0 + 16) * S::KROW + df * 16, S::KROW, lane));
+                    const F8 gT = tr_pair<T>(lds_tr_block(Gc + r0 * S::KROW + df * 16, S::KROW, lane),
+                                             lds_tr_block(Gc + (r0 + 16) * S::KROW + df * 16, S::KROW, lane));
 #pragma unroll
                     for (int nf = 0; nf < NKW; ++nf) {
                         dv[nf][df] = Mma<T>::k32(pa[nf], gT, dv[nf][df]);
@@ -719,14 +717,12 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
                 }
                 const f32x4 lse4 = *reinterpret_cast<const f32x4*>(lc + qb * 16 + lq * 4);
                 const f32x4 del4 = *reinterpret_cast<const f32x4*>(dc + qb * 16 + lq * 4);
-                T qT[DF][4], gT[DF][4];  // transposed operands: lane = head-dim column, 4 query rows
+                tr4 qT[DF], gT[DF];  // transposed operands (lane = head-dim column, 4 query rows): one transposing read each
 #pragma unroll
-                for (int df = 0; df < DF; ++df)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        qT[df][e] = Qc[(qb * 16 + lq * 4 + e) * S::KROW + df * 16 + l15];
-                        gT[df][e] = Gc[(qb * 16 + lq * 4 + e) * S::KROW + df * 16 + l15];
-                    }
+                for (int df = 0; df < DF; ++df) {
+                    qT[df] = lds_tr_block(Qc + qb * 16 * S::KROW + df * 16, S::KROW, lane);
+                    gT[df] = lds_tr_block(Gc + qb * 16 * S::KROW + df * 16, S::KROW, lane);
+                }
 #pragma unroll
                 for (int nf = 0; nf < NKW; ++nf) {
                     f32x4 s2 = f32x4{0.f, 0.f, 0.f, 0.f}, dp2 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -745,8 +741,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
                     }
 #pragma unroll
                     for (int df = 0; df < DF; ++df) {
-                        dv[nf][df] = Mma<T>::k16(pa, gT[df], dv[nf][df]);
-                        dk[nf][df] = Mma<T>::k16(dsa, qT[df], dk[nf][df]);
+                        dv[nf][df] = Mma<T>::k16r(pa, gT[df], dv[nf][df]);
+                        dk[nf][df] = Mma<T>::k16r(dsa, qT[df], dk[nf][df]);
                     }
                 }
             }
