@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel from the host each step instead of replaying the recorded hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-noise", action="store_true",
+                    help="feed pre-drawn noise / timesteps instead of drawing them on the device inside the step")
     ap.add_argument("--cpu-steps", type=int, default=6, help="timed oracle steps of the CPU baseline (~3 s each on 16 cores)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --shared-gpu rehearses N ranks on one GPU")
     ap.add_argument("--shared-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -251,6 +253,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def run_step(i):
+        # the reference draws noise and timesteps inside the step (train_lora_dreambooth.py:824-832): so does the timed step
+        # here — on the device, in the prologue kernel (Philox4x32-10 keyed by (seed, optimizer step), rank-invariant);
+        # --host-noise feeds the pre-drawn tensors of synthetic_steps instead
+        lat, noise, t, ctx = data[i]
+        if args.host_noise:
+            return trainer.step(lat, noise, t, ctx)
+        return trainer.step(lat, None, None, ctx, seed=1000)
+
     if rank == 0:
         log(f"model + {len(data)} synthetic batches resident on {torch.cuda.get_device_name(local_rank)}; priming")
     # Setup, not measurement: one throw-away step on a scratch copy of the LoRA state so that MIOpen / hipBLASLt /
@@ -258,7 +269,7 @@ def main():
     snapshot = (trainer.slab.params.clone(), trainer.opt.exp_avg.clone(), trainer.opt.exp_avg_sq.clone(), trainer.opt.step_count,
                 trainer.opt.norm.clone())
     want_graph, trainer.capture_graph = trainer.capture_graph, False
-    trainer.step(*data[0])  # host-launched: solver searches and lazy initialisation happen here
+    run_step(0)  # host-launched: solver searches and lazy initialisation happen here
     torch.cuda.synchronize()
     if want_graph:
         # Launch-mode selection, still setup: record the graph, then time two host-launched and two replayed steps.
@@ -268,7 +279,7 @@ def main():
             torch.cuda.synchronize()
             t = time.perf_counter()
             for _ in range(n):
-                trainer.step(*data[0])
+                run_step(0)
             torch.cuda.synchronize()
             return (time.perf_counter() - t) / n
 
@@ -276,7 +287,7 @@ def main():
         trainer.capture_graph = True
         # records; a rank whose recording fails finishes this step host-launched with the SAME single whole-slab
         # all-reduce a replay issues (LoraTrainer._step_graph), so the collectives stay matched whatever happens
-        trainer.step(*data[0])
+        run_step(0)
         ok = torch.tensor([1.0 if trainer.capture_graph else 0.0], device=device)
         if world > 1:  # agree on the launch mode BEFORE any further step: the two modes bucket the exchange differently
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -297,14 +308,14 @@ def main():
         log("warm-up")
     losses = []
     for i in range(args.warmup):
-        losses.append(trainer.step(*data[i]))
+        losses.append(run_step(i))
     barrier()
     if rank == 0:
         log(f"timing {args.steps} steps")
     barrier()
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
-        losses.append(trainer.step(*data[i]))
+        losses.append(run_step(i))
     barrier()
     elapsed = time.perf_counter() - t0
     # Roofline pass: the SAME K steps again with start/stop events attached to every hot-path dispatch.  It is a
@@ -320,7 +331,7 @@ def main():
         barrier()
         t1 = time.perf_counter()
         for i in range(args.warmup, args.warmup + args.steps):
-            trainer.step(*data[i])
+            run_step(i)
         barrier()
         elapsed_prof = time.perf_counter() - t1
         if rank == 0:
@@ -357,7 +368,9 @@ def main():
                                    "fp32 accumulate + fp32 master LoRA, full train step (fwd+bwd+clip+AdamW)",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "lora_params": trainer.slab.numel, "final_loss": final_loss, "overflow": overflow,
-                       "hipgraph": bool(graph_used)},
+                       "hipgraph": bool(graph_used),
+                       "noise": "pre-drawn on the host" if args.host_noise else
+                                "drawn on the device inside the step (Philox4x32-10 prologue kernel, rank-invariant)"},
         }
         if prof:
             dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
