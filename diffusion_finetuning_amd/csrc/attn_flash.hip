@@ -413,41 +413,21 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Backward.  Three launches, no atomics, every output element written by exactly one workgroup:
-//   delta  : Δ[b,h,q] = Σ_c dO·O            (the softmax correction, one streaming pass)
-//   dQ     : query-owned like the forward — P is rebuilt from the saved log-sum-exp, dPᵀ = V·dOᵀ has the layout of
-//            Sᵀ, dS = P∘(dP − Δ)·scale feeds dQᵀ += Kᵀ·dSᵀ straight from registers (K staged a second time transposed)
+// Backward.  Two launches, no atomics, every output element written by exactly one workgroup:
+//   dQ     : query-owned like the forward — also computes Δ[b,h,q] = Σ_c dO·O (the softmax correction) for its rows from
+//            the dO fragments it holds and writes it out for the second launch.  P is rebuilt from the saved log-sum-exp,
+//            dPᵀ = V·dOᵀ has the layout of Sᵀ, dS = P∘(dP − Δ)·scale feeds dQᵀ += Kᵀ·dSᵀ straight from registers (K staged
+//            a second time transposed)
 //   dK, dV : key-owned — a wave keeps the K and V fragments of its keys in registers and walks over ALL query tiles
 //            (Q, dO, LSE, Δ staged in LDS, shared by the four waves); S = Q·Kᵀ is taken with the query fragment FIRST,
 //            so its accumulators already are MFMA 16x16x16 operands with the keys along the lanes and four query rows
 //            per lane — exactly what the contractions over the query rows (dV = Pᵀ·dO, dK = dSᵀ·Q) need.
 
-template <typename T>
-__global__ __launch_bounds__(256) void attn_flash_delta_kernel(const T* __restrict__ O, const T* __restrict__ dO,
-                                                                float* __restrict__ Delta, int B, int Tq, int H, int d) {
-    const int64_t total = (int64_t)B * Tq * H;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int h = (int)(i % H);
-        const int64_t bt = i / H;  // b*Tq + t
-        const T* o = O + bt * H * d + (int64_t)h * d;
-        const T* g = dO + bt * H * d + (int64_t)h * d;
-        float acc = 0.f;
-        for (int c = 0; c < d; c += 8) {
-            const Chunk<T> a = *reinterpret_cast<const Chunk<T>*>(o + c);
-            const Chunk<T> b = *reinterpret_cast<const Chunk<T>*>(g + c);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc = fmaf(to_f32<T>(a.v[e]), to_f32<T>(b.v[e]), acc);
-        }
-        const int64_t b_ = bt / Tq, t = bt - b_ * Tq;
-        Delta[(b_ * H + h) * Tq + t] = acc;
-    }
-}
-
 template <typename T, int KS, int DF, int RB>
 __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const T* __restrict__ Q, const T* __restrict__ K,
-                                                             const T* __restrict__ V, const T* __restrict__ dO,
-                                                             const float* __restrict__ LSE,
-                                                             const float* __restrict__ Delta, T* __restrict__ dQ, int Tq,
+                                                             const T* __restrict__ V, const T* __restrict__ O,
+                                                             const T* __restrict__ dO, const float* __restrict__ LSE,
+                                                             float* __restrict__ Delta, T* __restrict__ dQ, int Tq,
                                                              int Tk, int H, int d, float scale, float scale_log2e,
                                                              int64_t ldq, int64_t ld_dq) {
     using S = FlashShape<KS, DF>;
@@ -477,7 +457,17 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const T* __restri
         load_row_frags<T, KS>(Q + ((int64_t)b * Tq + t) * ldq + h * d, Q, valid, d, lq, qf[rb]);
         load_row_frags<T, KS>(dO + roff, dO, valid, d, lq, gf[rb]);
         lse[rb] = valid ? LSE[(int64_t)bh * Tq + t] : INFINITY;  // +inf: probability 0 for rows past the end
-        delta[rb] = valid ? Delta[(int64_t)bh * Tq + t] : 0.f;
+        // Δ = Σ_c dO·O of the row (the softmax correction), computed here from the dO fragments the kernel holds anyway and
+        // written out for the dK/dV kernel, which is launched AFTER this one: no separate pass over O and dO
+        F8 of[KS];
+        load_row_frags<T, KS>(O + roff, O, valid, d, lq, of);
+        float dsum = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dsum = fmaf(to_f32<T>(of[ks][e]), to_f32<T>(gf[rb][ks][e]), dsum);
+        delta[rb] = quad_sum(dsum);
+        if (valid && lq == 0) Delta[(int64_t)bh * Tq + t] = delta[rb];
 #pragma unroll
         for (int df = 0; df < DF; ++df) acc[rb][df] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -851,11 +841,19 @@ struct FlashBwdArgs {
 template <typename T, int KS, int DF, int RBQ, int NKW>
 int launch_flash_bwd(const FlashBwdArgs& a, hipStream_t stream) {
     const float l2e = a.scale * 1.4426950408889634f;
+    // dQ first: it also produces Δ = Σ dO·O, which the dK/dV kernel reads
     {
-        const int64_t rows = (int64_t)a.B * a.Tq * a.H;
-        const unsigned blocks = (unsigned)((rows + 255) / 256 > 4096 ? 4096 : (rows + 255) / 256);
-        hipLaunchKernelGGL(attn_flash_delta_kernel<T>, dim3(blocks), dim3(256), 0, stream, static_cast<const T*>(a.O),
-                           static_cast<const T*>(a.dO), a.delta, a.B, a.Tq, a.H, a.d);
+        constexpr int lds = flash_dq_lds<KS, DF>();
+        auto kern = attn_flash_dq_kernel<T, KS, DF, RBQ>;
+        if (lds > 48 * 1024) {
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (attr != hipSuccess) return LORA_E_LAUNCH;
+        }
+        const dim3 grid((unsigned)((a.Tq + 64 * RBQ - 1) / (64 * RBQ)), (unsigned)(a.B * a.H));
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, static_cast<const T*>(a.Q), static_cast<const T*>(a.K),
+                           static_cast<const T*>(a.V), static_cast<const T*>(a.O), static_cast<const T*>(a.dO), a.LSE,
+                           a.delta, static_cast<T*>(a.dQ), a.Tq, a.Tk, a.H, a.d, a.scale, l2e, a.ldq, a.ld_dq);
         LORA_LAUNCH_CHECK();
     }
     {
@@ -871,20 +869,6 @@ int launch_flash_bwd(const FlashBwdArgs& a, hipStream_t stream) {
                            static_cast<const T*>(a.V), static_cast<const T*>(a.dO), a.LSE, a.delta,
                            static_cast<T*>(a.dK), static_cast<T*>(a.dV), a.Tq, a.Tk, a.H, a.d, a.scale, l2e, a.ldq,
                            a.ld_dq);
-        LORA_LAUNCH_CHECK();
-    }
-    {
-        constexpr int lds = flash_dq_lds<KS, DF>();
-        auto kern = attn_flash_dq_kernel<T, KS, DF, RBQ>;
-        if (lds > 48 * 1024) {
-            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            if (attr != hipSuccess) return LORA_E_LAUNCH;
-        }
-        const dim3 grid((unsigned)((a.Tq + 64 * RBQ - 1) / (64 * RBQ)), (unsigned)(a.B * a.H));
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, static_cast<const T*>(a.Q), static_cast<const T*>(a.K),
-                           static_cast<const T*>(a.V), static_cast<const T*>(a.dO), a.LSE, a.delta,
-                           static_cast<T*>(a.dQ), a.Tq, a.Tk, a.H, a.d, a.scale, l2e, a.ldq, a.ld_dq);
         LORA_LAUNCH_CHECK();
     }
     return LORA_OK;
