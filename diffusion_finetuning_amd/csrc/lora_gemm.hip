@@ -67,6 +67,7 @@ struct GemmParams {
     // epilogue writes C2[M, gateF] = h·gelu(g) next to C (C may be null: nothing is saved for a backward pass).
     void* C2;
     int gateF;
+    int dbg;  // tools/gemm_bench.py ablations (LORA_GEMM_DBG, timing only — results are wrong): 1 = no DMA after the prologue, 2 = no MFMA work
 };
 
 constexpr int kRowBytes = 128;  // one K-step of one tile row
@@ -425,12 +426,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
             if (kt == 0) STAMP(3);
             char* const refill = smem + (buf >= 1 ? buf - 1 : kStages - 1) * STAGE;  // the buffer read last step
             if (kt + DIST < nk) {
-                issue(kt + DIST, buf >= 1 ? buf - 1 : kStages - 1);
+                if (!(p.dbg & 1)) issue(kt + DIST, buf >= 1 ? buf - 1 : kStages - 1);
             } else if (MAIN && kt == nk - 1 && p.splitk <= 1) {
                 sQ = refill + QOFF;  // nothing left to prefetch: the epilogue's Q tile takes the free buffer
                 issue_q(sQ);
             }
-            compute(smem + buf * STAGE, kt);
+            if (!(p.dbg & 2)) compute(smem + buf * STAGE, kt);
             buf = buf + 1 == kStages ? 0 : buf + 1;
         }
     } else {
@@ -1058,7 +1059,9 @@ int forced_tile() {  // tuning knob for tools/gemm_bench.py only
 //    barrier latency.  Not instantiated either (the template still supports it).
 template <typename T, bool MAIN>
 int launch_pipe(const GemmParams& p_in, hipStream_t stream) {
-    const GemmParams& p = p_in;
+    GemmParams p = p_in;
+    static const int dbg_env = [] { const char* e = getenv("LORA_GEMM_DBG"); return e ? atoi(e) : 0; }();
+    p.dbg = dbg_env;
     if (!MAIN) return launch_tile<T, 64, 64, false, 3>(p, stream);
     static const int stg_env = [] { const char* e = getenv("LORA_FORCE_STAGES"); return e ? atoi(e) : 0; }();
     if (p.splitk > 1) return launch_tile<T, 128, 128, true, 2>(p, stream);

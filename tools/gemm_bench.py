@@ -10,6 +10,7 @@ COLD = "--cold" in sys.argv or "--cold-read" in sys.argv  # in-model conditions:
 _flush = None
 def run(fn, iters=20, warm=None):
     global _flush
+    iters = int(os.environ.get("GB_ITERS", iters))
     if COLD:
         if _flush is None: _flush = torch.empty(600 * 1024 * 1024, dtype=torch.uint8, device=dev)
         inner = fn
@@ -32,7 +33,8 @@ def run(fn, iters=20, warm=None):
 def per_shape():
     dtype = torch.float16
     print("tile", os.environ.get("LORA_FORCE_TILE"), "stages", os.environ.get("LORA_FORCE_STAGES"))
-    for (M,K,N) in SHAPES:
+    sel = os.environ.get("GB_SHAPES")
+    for (M,K,N) in ([SHAPES[int(i)] for i in sel.split(",")] if sel else SHAPES):
         x = torch.randn(M,K,device=dev).to(dtype); w = (torch.randn(N,K,device=dev)/K**0.5).to(dtype); wt = w.t().contiguous()
         a = torch.randn(4,K,device=dev)/4; b = torch.randn(N,4,device=dev)*0.05; dy = torch.randn(M,N,device=dev).to(dtype)
         y, t = nat.lora_linear_fwd(x,w,None,a,b,1.0); dx,u = nat.lora_linear_bwd_input(dy,wt,a,b,1.0,True)
