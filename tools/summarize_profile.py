@@ -18,17 +18,21 @@ import sys
 
 
 def short(name):
-    m = re.search(r"(lora_\w+kernel|ddpm_mse_kernel|add_noise_kernel|reduce_partials_kernel|pack_factors\w*|grad_sqnorm_kernel|adamw_kernel)", name)
+    m = re.search(r"(lora_\w+kernel|ddpm_mse_kernel|add_noise_kernel|noise_prologue_kernel|reduce_partials_kernel|pack_factors\w*|grad_sqnorm_kernel|adamw_kernel)", name)
     if not m:
         return name[:80]
     t = re.search(r"I(DF16_|DF16b|f)(?:Li(\d+)E)?(?:Li(\d+)E)?(?:Lb(\d)E)?(?:Lb(\d)E)?", name)
     return m.group(1) + ("<" + ",".join(x for x in t.groups() if x) + ">" if t else "")
 
 
+def _step_start(name):  # the first hot-path kernel of a train step: the noise prologue (device draw) or add_noise (host draw)
+    return "add_noise_kernel" in name or "noise_prologue_kernel" in name
+
+
 def trace(path, warmup, out):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    starts = [int(r["Start_Timestamp"]) for r in rows if "add_noise_kernel" in r["Kernel_Name"]]
+    starts = [int(r["Start_Timestamp"]) for r in rows if _step_start(r["Kernel_Name"])]
     t0 = starts[warmup]
     steps = len(starts) - warmup
     agg = collections.defaultdict(list)
@@ -83,7 +87,7 @@ def shapes(path, warmup):
     """In-model time of every hot-path launch class: dispatches of the timed region grouped by (kernel, grid, LDS)."""
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    starts = [int(r["Start_Timestamp"]) for r in rows if "add_noise_kernel" in r["Kernel_Name"]]
+    starts = [int(r["Start_Timestamp"]) for r in rows if _step_start(r["Kernel_Name"])]
     t0 = starts[warmup]
     steps = len(starts) - warmup
     agg = collections.defaultdict(list)
