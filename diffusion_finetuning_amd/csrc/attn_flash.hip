@@ -4,8 +4,10 @@
 //
 // Same conventions as attn_ctx.hip: tensors stay [B, T, H·d] (what the LoRA linears produce and consume), MFMA 16x16x32
 // with the key fragment as the FIRST operand so that a lane owns one query row (softmax statistics are per lane, two
-// cross-lane steps per reduction) and the probability registers feed the P·V product directly; V is staged transposed
-// with the keys permuted to that register order.  New here: 64-key tiles double-buffered in LDS (global → registers
+// cross-lane steps per reduction) and the probability registers feed the P·V product directly; K and V tiles are staged
+// row-major and the products that contract over the keys fetch their Vᵀ / Kᵀ fragments with the transposing LDS read
+// (ds_read_b64_tr_b16: two block reads deliver a lane's 8 keys in exactly that register order — no transposed copy, no
+// 2-byte scatter writes: d = 160 forward 22 → 13 µs, d = 80 41 → 34 µs).  New here: 64-key tiles double-buffered in LDS (global → registers
 // at the top of an iteration, registers → LDS after the tile's arithmetic), running max / sum with accumulator
 // rescaling, several 16-row blocks per wave so that every K / V fragment read from LDS is used RB times, and the
 // row-wise log-sum-exp (base 2, of the scaled scores) written out for the backward kernels.
@@ -23,20 +25,16 @@ template <int KS, int DF> struct FlashShape {
     static constexpr int DP = KS * 32;
     static constexpr int DV = DF * 16;
     static constexpr int KROW = DP + 8;     // halfs per K row in LDS (+16 B against bank conflicts)
-    static constexpr int TROW = kTile + 8;  // halfs per Vᵀ row
     static constexpr int CPR = DP / 8;      // 16-byte chunks per key row
     static constexpr int N = kTile * CPR;
     static constexpr int IT = (N + 255) / 256;
     static constexpr int K_HALFS = kTile * KROW;
-    static constexpr int V_HALFS = DV * TROW;
 };
 
-template <int KS, int DF> constexpr int flash_fwd_lds_bytes() {
-    return 2 * (FlashShape<KS, DF>::K_HALFS + FlashShape<KS, DF>::V_HALFS) * 2;
-}
-template <int KS, int DF> constexpr int flash_dq_lds_bytes() {
-    return (4 * FlashShape<KS, DF>::K_HALFS + 2 * FlashShape<KS, DF>::V_HALFS) * 2;
-}
+// K and V tiles are both staged ROW-major ([64 keys][KROW]); the products that contract over the keys (P·V, dS·K) read them
+// with the transposing LDS read (ds_read_b64_tr_b16, attn_common.h) instead of from a second, transposed copy
+template <int KS, int DF> constexpr int flash_fwd_lds_bytes() { return 4 * FlashShape<KS, DF>::K_HALFS * 2; }
+template <int KS, int DF> constexpr int flash_dq_lds_bytes() { return 4 * FlashShape<KS, DF>::K_HALFS * 2; }
 template <int KS, int DF> constexpr int flash_dkdv_lds_bytes() { return 4 * FlashShape<KS, DF>::K_HALFS * 2 + 4 * 64 * 4; }
 
 // One 64-row tile of two [rows, H·d] tensors (K and V, or Q and dO) on its way global → registers → LDS.
@@ -48,7 +46,7 @@ template <typename T, int KS, int DF> struct TileStage {
     Chunk<T> a[S::IT], b[S::IT];
     int64_t src[S::IT];           // element offset of the chunk inside tile 0 of A
     int dld;                      // row stride of B minus row stride of A (uniform): B's offset = src + row·dld
-    int row[S::IT], rowoff[S::IT], troff[S::IT];  // row; offset in a row-major [64][KROW] tile; in a transposed [DV][TROW] one
+    int row[S::IT], rowoff[S::IT];  // row; offset in a row-major [64][KROW] tile
     bool have[S::IT];
     __device__ __forceinline__ void init(int d, int64_t lda, int64_t ldb) {
         const int cpr = d >> 3, n = kTile * cpr;
@@ -61,7 +59,6 @@ template <typename T, int KS, int DF> struct TileStage {
             row[i] = r;
             src[i] = (int64_t)r * lda + c;
             rowoff[i] = r * S::KROW + c;
-            troff[i] = c * S::TROW + key_pos(r);
         }
     }
     // A, B: first row of the tile in each tensor; rows_valid >= 64 for a full tile
@@ -96,22 +93,6 @@ template <typename T, int KS, int DF> struct TileStage {
 #pragma unroll
         for (int i = 0; i < S::IT; ++i)
             if (have[i]) *reinterpret_cast<Chunk<T>*>(dst + rowoff[i]) = b[i];
-    }
-    __device__ __forceinline__ void store_a_transposed(T* dst) const {
-#pragma unroll
-        for (int i = 0; i < S::IT; ++i)
-            if (have[i]) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) dst[troff[i] + e * S::TROW] = a[i].v[e];
-            }
-    }
-    __device__ __forceinline__ void store_b_transposed(T* dst) const {
-#pragma unroll
-        for (int i = 0; i < S::IT; ++i)
-            if (have[i]) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) dst[troff[i] + e * S::TROW] = b[i].v[e];
-            }
     }
 };
 
@@ -154,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restr
     using F8 = typename Mma<T>::F8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* Ks = reinterpret_cast<T*>(smem);            // [2][kTile][KROW]
-    T* Vt = Ks + 2 * S::K_HALFS;                    // [2][DV][TROW]
+    T* Vs = Ks + 2 * S::K_HALFS;                    // [2][kTile][KROW]
 
     const int bh = blockIdx.y;
     const int b = bh / H, h = bh - b * H;
@@ -186,21 +167,28 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restr
     lds_zero(smem, flash_fwd_lds_bytes<KS, DF>());
     __syncthreads();
     if constexpr (ONES) {  // never re-staged: the stage writes rows < d only
-        if (threadIdx.x < 2 * kTile) Vt[(threadIdx.x >> 6) * S::V_HALFS + d * S::TROW + (threadIdx.x & 63)] = from_f32<T>(1.f);
+        if (threadIdx.x < 2 * kTile) Vs[(threadIdx.x >> 6) * S::K_HALFS + (threadIdx.x & 63) * S::KROW + d] = from_f32<T>(1.f);
     }
     TileStage<T, KS, DF> stage;
     stage.init(d, ldq, ldq);
     stage.load(Kh, Vh, Tk);
     stage.store_a_rows(Ks);
-    stage.store_b_transposed(Vt);
+    stage.store_b_rows(Vs);
     __syncthreads();
     const int n_tiles = (Tk + kTile - 1) / kTile;
+    // Vᵀ fragment (df, kk) for the P·V product: lane = head-dim column df*16 + l15, its 8 contraction slots are the keys
+    // kk*32 + {0,16} + lq*4 + (0..3) — the order in which two neighbouring score fragments sit in a lane's registers —
+    // i.e. two transposing block reads of the row-major V tile
+    auto vt_frag = [&](const T* Vc, int df, int kk) {
+        return tr_pair<T>(lds_tr_block(Vc + (kk * 32) * S::KROW + df * 16, S::KROW, lane),
+                          lds_tr_block(Vc + (kk * 32 + 16) * S::KROW + df * 16, S::KROW, lane));
+    };
     // one key tile; RAGGED (only ever the last tile) is a compile-time flag so that full tiles carry no masking code
     auto tile = [&](int kt, auto ragged_tag) {
         constexpr bool RAGGED = decltype(ragged_tag)::value;
         const int cur = kt & 1;
         const T* Kc = Ks + cur * S::K_HALFS;
-        const T* Vc = Vt + cur * S::V_HALFS;
+        const T* Vc = Vs + cur * S::K_HALFS;
         if (kt + 1 < n_tiles) stage.load(Kh + (int64_t)(kt + 1) * kTile * ldq, Vh + (int64_t)(kt + 1) * kTile * ldq, Tk - (kt + 1) * kTile);  // in flight during this tile's work
 
         // Narrow heads (the fragments of a whole tile fit the register file): software pipeline, below.  Wide heads keep the
@@ -218,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restr
             };
             auto vfrag = [&](int df, int kk) {
                 if constexpr (RES) return vf[df][kk];
-                else return *reinterpret_cast<const F8*>(Vc + (df * 16 + l15) * S::TROW + kk * 32 + lq * 8);
+                else return vt_frag(Vc, df, kk);
             };
             if constexpr (RES) {
     #pragma unroll
@@ -230,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restr
                 for (int df = 0; df < DF; ++df)
     #pragma unroll
                     for (int kk = 0; kk < kNKF / 2; ++kk)
-                        vf[df][kk] = *reinterpret_cast<const F8*>(Vc + (df * 16 + l15) * S::TROW + kk * 32 + lq * 8);
+                        vf[df][kk] = vt_frag(Vc, df, kk);
             }
             auto scores = [&](int rb, f32x4 (&sc)[kNKF]) {  // Sᵀ = K·Qᵀ for one 16-row block
     #pragma unroll
@@ -373,14 +361,14 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restr
             for (int df = 0; df < DF; ++df)
     #pragma unroll
                 for (int kk = 0; kk < kNKF / 2; ++kk) {
-                    const F8 vf = *reinterpret_cast<const F8*>(Vc + (df * 16 + l15) * S::TROW + kk * 32 + lq * 8);
+                    const F8 vf = vt_frag(Vc, df, kk);
     #pragma unroll
                     for (int rb = 0; rb < RB; ++rb) o[rb][df] = Mma<T>::k32(vf, pf[rb][kk], o[rb][df]);
                 }
         }
         if (kt + 1 < n_tiles) {
             stage.store_a_rows(Ks + (cur ^ 1) * S::K_HALFS);
-            stage.store_b_transposed(Vt + (cur ^ 1) * S::V_HALFS);
+            stage.store_b_rows(Vs + (cur ^ 1) * S::K_HALFS);
         }
         __syncthreads();
     };
@@ -435,7 +423,6 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const T* __restri
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* Ks = reinterpret_cast<T*>(smem);   // [2][kTile][KROW]
     T* Vs = Ks + 2 * S::K_HALFS;           // [2][kTile][KROW]
-    T* Kt = Vs + 2 * S::K_HALFS;           // [2][DV][TROW]
 
     const int bh = blockIdx.y;
     const int b = bh / H, h = bh - b * H;
@@ -479,7 +466,6 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const T* __restri
     stage.load(Kh, Vh, Tk);
     stage.store_a_rows(Ks);
     stage.store_b_rows(Vs);
-    stage.store_a_transposed(Kt);
     __syncthreads();
     const int n_tiles = (Tk + kTile - 1) / kTile;
     auto tile = [&](int kt, auto ragged_tag) {
@@ -487,7 +473,6 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const T* __restri
         const int cur = kt & 1;
         const T* Kc = Ks + cur * S::K_HALFS;
         const T* Vc = Vs + cur * S::K_HALFS;
-        const T* Ktc = Kt + cur * S::V_HALFS;
         if (kt + 1 < n_tiles) stage.load(Kh + (int64_t)(kt + 1) * kTile * ldq, Vh + (int64_t)(kt + 1) * kTile * ldq, Tk - (kt + 1) * kTile);
 
         f32x4 s[RB][kNKF], dp[RB][kNKF];
@@ -529,14 +514,15 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const T* __restri
         for (int df = 0; df < DF; ++df)
 #pragma unroll
             for (int kk = 0; kk < kNKF / 2; ++kk) {
-                const F8 ktf = *reinterpret_cast<const F8*>(Ktc + (df * 16 + l15) * S::TROW + kk * 32 + lq * 8);
+                // Kᵀ fragment: lane = head-dim column, slots = keys kk*32 + {0,16} + lq*4 + (0..3): two transposing block reads
+                const F8 ktf = tr_pair<T>(lds_tr_block(Kc + (kk * 32) * S::KROW + df * 16, S::KROW, lane),
+                                          lds_tr_block(Kc + (kk * 32 + 16) * S::KROW + df * 16, S::KROW, lane));
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) acc[rb][df] = Mma<T>::k32(ktf, dsf[rb][kk], acc[rb][df]);
             }
         if (kt + 1 < n_tiles) {
             stage.store_a_rows(Ks + (cur ^ 1) * S::K_HALFS);
             stage.store_b_rows(Vs + (cur ^ 1) * S::K_HALFS);
-            stage.store_a_transposed(Kt + (cur ^ 1) * S::V_HALFS);
         }
         __syncthreads();
     };
