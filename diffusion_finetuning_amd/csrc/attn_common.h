@@ -17,6 +17,9 @@ template <> struct Mma<half_t> {
         const f16x4 av = {a[0], a[1], a[2], a[3]}, bv = {b[0], b[1], b[2], b[3]};
         return __builtin_amdgcn_mfma_f32_16x16x16f16(av, bv, c, 0, 0, 0);
     }
+    static __device__ __forceinline__ f32x4 k16rr(s16x4 a, s16x4 b, f32x4 c) {  // both operands as raw 16-bit quads
+        return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
+    }
     static __device__ __forceinline__ f32x4 k16r(const half_t* a, s16x4 b, f32x4 c) {  // b: four raw 16-bit values
         const f16x4 av = {a[0], a[1], a[2], a[3]};
         return __builtin_amdgcn_mfma_f32_16x16x16f16(av, __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
@@ -35,6 +38,9 @@ template <> struct Mma<bf16_t> {
             bv[e] = __builtin_bit_cast(short, b[e]);
         }
         return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bv, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 k16rr(s16x4 a, s16x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
     }
     static __device__ __forceinline__ f32x4 k16r(const bf16_t* a, s16x4 b, f32x4 c) {
         s16x4 av;
@@ -55,6 +61,11 @@ template <typename T>
 __device__ __forceinline__ tr4 lds_tr_block(const T* rows, int row_stride, int lane) {
     const int l15 = lane & 15, g = lane >> 4;
     const T* p = rows + (g * 4 + (l15 >> 2)) * row_stride + (l15 & 3) * 4;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4*)(p));
+}
+// the same read with the lane's own address (4 contiguous elements of its row; 8-byte aligned): the 16 "columns" a group
+// delivers need not be contiguous — column 4p+j is element j at the address lane 4q+p supplies
+template <typename T> __device__ __forceinline__ tr4 lds_tr_at(const T* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4*)(p));
 }
 template <typename T> __device__ __forceinline__ typename Mma<T>::F8 tr_pair(tr4 lo, tr4 hi) {  // two blocks → one 8-wide operand

@@ -13,8 +13,9 @@
 // rows; a wave works on blocks of 16 query rows with MFMA 16x16x32:
 //   Sᵀ = K·Qᵀ  with the K fragment as the FIRST operand, so a lane owns one query row and 4 consecutive keys per
 //   fragment: the softmax row reductions are in-lane plus two cross-lane steps, and the probability registers are
-//   directly the second operand of the next product (contraction over keys) — P never goes through LDS.  V (and K
-//   for dQ) sit in LDS transposed with the keys permuted to match that register order.
+//   directly the second operand of the next product (contraction over keys) — P never goes through LDS.  K and V sit in
+//   LDS row-major only; the Vᵀ (and, for dQ, Kᵀ) fragments come from the transposing LDS read (ds_read_b64_tr_b16), which
+//   delivers a lane's keys in exactly that register order.
 // Backward recomputes P from Q and K (cheap: one tile), uses Σ_key P·dP for the softmax correction (so O is not
 // needed), writes dQ directly, and accumulates dK/dV over the chunk in registers (MFMA 16x16x16, contraction over the
 // 16 query rows; P, dS, Q and dO are re-read transposed from small per-wave LDS tiles for that).  Per-workgroup fp32 partials are
@@ -54,20 +55,6 @@ template <typename T, int KS, int DF, int NKF> struct StageRegs {
             const int idx = threadIdx.x + i * 256;
             const int key = idx / CPR, c = (idx - key * CPR) * 8;
             if (idx < N) *reinterpret_cast<Chunk<T>*>(dst + key * S::KROW + c) = v[i];
-        }
-    }
-    // transposed [DV][TROW] with the keys permuted (operand rows = head dim, contraction over keys)
-    // (only the head-dim columns c0 .. c0 + DV - 1: the slice this workgroup produces)
-    __device__ __forceinline__ void store_transposed(T* dst, int c0) const {
-#pragma unroll
-        for (int i = 0; i < IT; ++i) {
-            const int idx = threadIdx.x + i * 256;
-            const int key = idx / CPR, c = (idx - key * CPR) * 8 - c0;
-            if (idx < N && c >= 0 && c < S::DV) {
-                const int pos = key_pos(key);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) dst[(c + e) * S::TROW + pos] = v[i].v[e];
-            }
         }
     }
 };
@@ -115,7 +102,7 @@ __global__ __launch_bounds__(256) void attn_ctx_fwd_kernel(const T* __restrict__
     using F8 = typename Mma<T>::F8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* Ks = reinterpret_cast<T*>(smem);          // [NK][KROW]
-    T* Vt = Ks + S::NK * S::KROW;                 // [DV][TROW]
+    T* Vs = Ks + S::NK * S::KROW;                 // [NK][KROW]  row-major; Vᵀ fragments by transposing LDS reads
 
     const int chunk = blockIdx.x % chunks;
     const int bh = blockIdx.x / chunks;
@@ -129,7 +116,7 @@ __global__ __launch_bounds__(256) void attn_ctx_fwd_kernel(const T* __restrict__
         kr.load(K + (int64_t)b * Tk * ldk + h * d, ldk, Tk, d);  // K/V may be column slices of a wider buffer
         vr.load(V + (int64_t)b * Tk * ldk + h * d, ldk, Tk, d);
         kr.store_rows(Ks);
-        vr.store_transposed(Vt, 0);
+        vr.store_rows(Vs);
     }
     __syncthreads();
 
@@ -169,7 +156,9 @@ __global__ __launch_bounds__(256) void attn_ctx_fwd_kernel(const T* __restrict__
             f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < NKF / 2; ++kk) {
-                const F8 vf = *reinterpret_cast<const F8*>(Vt + (df * 16 + l15) * S::TROW + kk * 32 + lq * 8);
+                // lane = head-dim column; slots = keys kk*32 + {0,16} + lq*4 + (0..3), the order of the P registers
+                const F8 vf = tr_pair<T>(lds_tr_block(Vs + (kk * 32) * S::KROW + df * 16, S::KROW, lane),
+                                         lds_tr_block(Vs + (kk * 32 + 16) * S::KROW + df * 16, S::KROW, lane));
                 o = Mma<T>::k32(vf, pf[kk], o);
             }
             const int c = df * 16 + lq * 4;  // the lane owns head-dim values c..c+3 of query row t
@@ -185,16 +174,6 @@ __global__ __launch_bounds__(256) void attn_ctx_fwd_kernel(const T* __restrict__
     }
 }
 
-// transposed fragments for the contraction over the 16 query rows: lane = (head-dim column l15, rows lq*4 .. +3),
-// read from the wave's own LDS copy of the block's rows ([16][KROW], zero beyond the valid rows and d)
-template <typename T, int DF, int KROW>
-__device__ __forceinline__ void load_col_frags(const T* tile, int c0, int l15, int lq, T (&f)[DF][4]) {
-#pragma unroll
-    for (int df = 0; df < DF; ++df)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) f[df][e] = tile[(lq * 4 + e) * KROW + c0 + df * 16 + l15];
-}
-
 template <typename T, int KS, int DF, int NKF>
 __global__ __launch_bounds__(256) void attn_ctx_bwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
                                                             const T* __restrict__ V, const T* __restrict__ dO,
@@ -206,10 +185,9 @@ __global__ __launch_bounds__(256) void attn_ctx_bwd_kernel(const T* __restrict__
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* Ks = reinterpret_cast<T*>(smem);          // [NK][KROW]   rows = keys, for Sᵀ and S
     T* Vs = Ks + S::NK * S::KROW;                 // [NK][KROW]   rows = keys, for dPᵀ and dP
-    T* Kt = Vs + S::NK * S::KROW;                 // [DV][TROW]   for dQ
-    T* Qw = Kt + S::DV * S::TROW + (threadIdx.x >> 6) * 2 * 16 * S::KROW;  // this wave's [16][KROW] copy of its Q rows
+    T* Qw = Vs + S::NK * S::KROW + (threadIdx.x >> 6) * 2 * 16 * S::KROW;  // this wave's [16][KROW] copy of its Q rows
     T* Gw = Qw + 16 * S::KROW;                    //                            ... and of its dO rows
-    T* Pw = Kt + S::DV * S::TROW + 4 * 2 * 16 * S::KROW + (threadIdx.x >> 6) * 2 * 16 * S::TROW;  // wave's P  [16][TROW]
+    T* Pw = Vs + S::NK * S::KROW + 4 * 2 * 16 * S::KROW + (threadIdx.x >> 6) * 2 * 16 * S::TROW;  // wave's P  [16][TROW]
     T* Sw = Pw + 16 * S::TROW;                                                                      // wave's dS [16][TROW]
     float* red = reinterpret_cast<float*>(smem);  // overlay after the main loop: [2][NK][DV]
 
@@ -226,7 +204,6 @@ __global__ __launch_bounds__(256) void attn_ctx_bwd_kernel(const T* __restrict__
         kr.load(K + (int64_t)b * Tk * ldk + h * d, ldk, Tk, d);  // K/V may be column slices of a wider buffer
         vr.load(V + (int64_t)b * Tk * ldk + h * d, ldk, Tk, d);
         kr.store_rows(Ks);
-        kr.store_transposed(Kt, c0);
         vr.store_rows(Vs);
     }
     __syncthreads();
@@ -301,7 +278,9 @@ __global__ __launch_bounds__(256) void attn_ctx_bwd_kernel(const T* __restrict__
                 f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kk = 0; kk < NKF / 2; ++kk) {
-                    const F8 kf = *reinterpret_cast<const F8*>(Kt + (df * 16 + l15) * S::TROW + kk * 32 + lq * 8);
+                    // Kᵀ fragment of this head-dim slice from the row-major K tile (two transposing block reads)
+                    const F8 kf = tr_pair<T>(lds_tr_block(Ks + (kk * 32) * S::KROW + c0 + df * 16, S::KROW, lane),
+                                             lds_tr_block(Ks + (kk * 32 + 16) * S::KROW + c0 + df * 16, S::KROW, lane));
                     g = Mma<T>::k32(kf, dsf[kk], g);
                 }
                 const int c = c0 + df * 16 + lq * 4;
@@ -316,22 +295,23 @@ __global__ __launch_bounds__(256) void attn_ctx_bwd_kernel(const T* __restrict__
 
         // ---- dK, dV: contraction over the 16 query rows.  Operands with the keys (resp. head-dim columns) along the
         // lanes and 4 query rows per lane, read back transposed from the wave's LDS tiles --------------------------
-        T qT[DF][4], gT[DF][4];
-        load_col_frags<T, DF, S::KROW>(Qw, c0, l15, lq, qT);
-        load_col_frags<T, DF, S::KROW>(Gw, c0, l15, lq, gT);
+        // (transposing LDS reads: one ds_read_b64_tr_b16 per operand instead of four 2-byte reads and packing)
+        tr4 qT[DF], gT[DF];  // lane = head-dim column c0 + df*16 + l15, the block's rows lq*4 .. +3
+#pragma unroll
+        for (int df = 0; df < DF; ++df) {
+            qT[df] = lds_tr_block(Qw + c0 + df * 16, S::KROW, lane);
+            gT[df] = lds_tr_block(Gw + c0 + df * 16, S::KROW, lane);
+        }
 #pragma unroll
         for (int nf = 0; nf < NKF; ++nf) {
-            const int pos = (nf >> 1) * 32 + ((l15 >> 2) << 3) + (nf & 1) * 4 + (l15 & 3);  // key_pos(nf*16 + l15)
-            T pa[4], dsa[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                pa[e] = Pw[(lq * 4 + e) * S::TROW + pos];
-                dsa[e] = Sw[(lq * 4 + e) * S::TROW + pos];
-            }
+            // lane = key nf*16 + l15, which sits at position key_pos(...) = (nf>>1)*32 + 8·(l15>>2) + 4·(nf&1) + (l15&3) of a P row:
+            // lane 4q+p of a group supplies row lq*4 + q, the four positions of key group p
+            const int off = (lq * 4 + (l15 >> 2)) * S::TROW + (nf >> 1) * 32 + (l15 & 3) * 8 + (nf & 1) * 4;
+            const tr4 pa = lds_tr_at(Pw + off), dsa = lds_tr_at(Sw + off);
 #pragma unroll
             for (int df = 0; df < DF; ++df) {
-                dv[nf][df] = Mma<T>::k16(pa, gT[df], dv[nf][df]);
-                dk[nf][df] = Mma<T>::k16(dsa, qT[df], dk[nf][df]);
+                dv[nf][df] = Mma<T>::k16rr(pa, gT[df], dv[nf][df]);
+                dk[nf][df] = Mma<T>::k16rr(dsa, qT[df], dk[nf][df]);
             }
         }
 #pragma unroll
@@ -441,11 +421,11 @@ bool plan_ctx(int B, int Tq, int Tk, int H, int d, bool backward, CtxPlan* pl) {
 
 template <int KS, int DF, int NKF> constexpr int fwd_lds() {
     using S = CtxShape<KS, DF, NKF>;
-    return (S::NK * S::KROW + S::DV * S::TROW) * 2;
+    return 2 * S::NK * S::KROW * 2;
 }
 template <int KS, int DF, int NKF> constexpr int bwd_lds() {
     using S = CtxShape<KS, DF, NKF>;
-    constexpr int stage = (2 * S::NK * S::KROW + S::DV * S::TROW + 4 * 2 * 16 * S::KROW + 4 * 2 * 16 * S::TROW) * 2;
+    constexpr int stage = (2 * S::NK * S::KROW + 4 * 2 * 16 * S::KROW + 4 * 2 * 16 * S::TROW) * 2;
     constexpr int red = 2 * S::NK * S::DV * 4;
     return stage > red ? stage : red;
 }
