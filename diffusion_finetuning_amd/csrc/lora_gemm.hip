@@ -10,24 +10,29 @@
 // orientations.  F arrives PACKED: [16, Kc] in the compute dtype, rows ≥ r zero
 // (lora_pack_factors), so it is staged exactly like an operand tile.
 //
-// Structure per workgroup of NW waves (2 row waves × NW/2 column waves; 256 or 512 threads), BM×BN output tile,
-// 128-byte K-steps:
-//   - PIPE main loop: a 3-stage LDS ring filled by LDS-DMA (global_load_lds, 16 B per lane, no VGPR
-//     staging), two K-steps in flight behind a COUNTED s_waitcnt vmcnt and one raw s_barrier per step.
-//     The XOR swizzle of the 16-B chunks is applied to the per-lane SOURCE address (the DMA writes LDS in
-//     lane order) and again on the fragment reads, which are then bank-conflict-free ds_read_b128.
-//   - fallback main loop (contraction not a multiple of the K-step): register-staged, 2 barriers per step.
+// Structure per workgroup of NW waves (2 row waves × NW/2 column waves; 256 threads in every instantiated form), BM×BN output
+// tile (128×128, 128×160, 64×128, 64×64), 128-byte K-steps:
+//   - PIPE main loop: an LDS ring of STG = 2–4 stages filled by LDS-DMA (global_load_lds, 16 B per lane, no VGPR staging),
+//     STG−1 K-steps in flight behind a COUNTED s_waitcnt vmcnt and one raw s_barrier per step.  The XOR swizzle of the 16-B
+//     chunks is applied to the per-lane SOURCE address (the DMA writes LDS in lane order) and again on the fragment reads,
+//     which are then bank-conflict-free ds_read_b128.  Two workgroups per CU by construction (≤ 80 KB LDS, ≤ 256 registers);
+//   - fallback main loop (contraction not a multiple of the K-step): register-staged, 2 barriers per step;
 //   - base contraction on MFMA 16x16x32 (f16/bf16) or 16x16x4 (f32, exact), issued with the Bm fragment as the
 //     first operand: a lane then owns 4 CONSECUTIVE COLUMNS of one output row (and 4 consecutive rank entries of
 //     P), so the epilogue moves 8/16 bytes per LDS access instead of one element;
 //   - the rank-r factor rides along as a 16-row tile: the X fragments already in VGPRs are multiplied
 //     with it (one extra MFMA per row fragment, K-steps split between the two column waves), so T
 //     costs no extra HBM or LDS traffic for X;
-//   - epilogue: the two partial P tiles are summed through LDS, P is written once, and s·P·Qᵀ is added
-//     to the accumulators as ONE extra MFMA K-step: for 16-bit types the 32-wide step carries
-//     [hi(sP) | lo(sP)] × [Q | Q], keeping P at ~fp32 precision;
-//   - bias is added in fp32, the tile is transposed through LDS and stored as whole 16-B row chunks.
-// Workgroups are dealt to XCDs so that the column tiles of one row panel share an L2.
+//   - epilogue on the ring's own buffers: the partial P tiles of the column waves meet in the buffer that is free after the
+//     last K-step; thread (row, half) sums them, writes P out and leaves s·P as ONE packed record per row — a high and a low
+//     16-bit part in MFMA operand order — so every wave fetches a fragment with one 16-byte read and s·P·Qᵀ enters the
+//     accumulators as ONE extra MFMA K-step ([hi | lo] × [Q | Q]: P keeps ~fp32 precision).  The Q tile itself is fetched by
+//     DMA during the last K-step into the same free buffer (no LDS of its own: what lets two 128×160 tiles share a CU);
+//   - bias is added in fp32, the tile is transposed through the buffer of the last K-step and stored as whole 16-B row chunks;
+//   - GATE instantiation (the `proj` layer of a GEGLU block): a column tile is 64 hidden columns plus the 64 gate columns behind
+//     them, and the store pass writes h·gelu(g) next to (or instead of) the [h | g] tile — diffusers GEGLU.forward in the epilogue.
+// Workgroups are dealt to XCDs so that the column tiles of one row panel (or the row tiles of one column panel, whichever
+// re-fetches the smaller operand) share an L2.  Tile / ring choice per shape: launch_pipe(), measured with cold weights.
 #include <cstdlib>
 
 #include "common.h"
@@ -1048,15 +1053,18 @@ int forced_tile() {  // tuning knob for tools/gemm_bench.py only
     return forced;
 }
 
-// Tile and ring-depth choice, from tools/gemm_bench.py sweeps on MI355X (profiles/README.md):
-//  * occupancy beats prefetch depth: a 2-stage ring lets two 128×128 workgroups share a CU (78 KB LDS each) and
+// Tile and ring-depth choice, from tools/gemm_bench.py sweeps on MI355X — hot and with cold weights (--cold-read) — and from
+// the in-model launch-class table (tools/summarize_profile.py shapes; profiles/README.md):
+//  * occupancy beats prefetch depth: a 2-stage ring lets two 128-row workgroups share a CU (≤ 78 KB LDS each) and
 //    is 25-35 % faster than the 3-stage ring at one workgroup per CU on every shape that fills the chip;
-//  * 128×128 once its grid has >= 128 tiles (and the last column tile is not mostly padding), else 64×64;
-//  * 64×64: 2 stages (3 workgroups per CU) when there are >= 512 tiles to overlap, 3 stages (deeper prefetch)
-//    for the small latency-bound grids.  128×64 never won and is not instantiated;
-//  * 256×128 (3-stage ring, one workgroup of 4 waves per CU, 128×64 wave tiles) is correct but 20-100 % slower than
-//    two independent 128×128 workgroups per CU on every hot-path shape: one wave per SIMD cannot hide its own LDS and
-//    barrier latency.  Not instantiated either (the template still supports it).
+//  * 128×160 for widths that are multiples of 160 but not of 128 (320, 960): no padding columns;
+//  * 128×128 once its grid has >= 256 tiles (and the last column tile is not mostly padding); 64×128 (2 stages) for
+//    128..255-tile grids, 64×128 behind a 3-stage ring for 64..127-tile grids;
+//  * 64×64 below that: 2 stages (3 workgroups per CU) when there are >= 512 tiles to overlap, else 3, or 4 stages on
+//    contractions of >= 8 K-steps (the 6-stage one-workgroup form lost once the weights are cold).  128×64 never won;
+//  * 256×128 / 128×256 (one 4- or 8-wave workgroup per CU, with or without a ping-pong DMA order) are correct but 5-100 %
+//    slower than two independent 128-row workgroups per CU on every hot-path shape.  Not instantiated (the template
+//    still supports them).
 template <typename T, bool MAIN>
 int launch_pipe(const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
