@@ -757,11 +757,13 @@ struct FlashPlan {
 bool plan_flash(int B, int Tq, int Tk, int H, int d, FlashPlan* pl) {
     if (B < 1 || Tq < 1 || Tk < 1 || H < 1 || d < 8 || (d % 8) != 0 || d > 160) return false;
     if (d <= 48) { pl->ks = 2; pl->df = 3; pl->rb = 4; pl->rb_dq = 2; pl->nkw = 4; }
-    else if (d <= 64) { pl->ks = 2; pl->df = 4; pl->rb = 4; pl->rb_dq = 2; pl->nkw = 4; }
+    else if (d <= 64) { pl->ks = 2; pl->df = 4; pl->rb = 4; pl->rb_dq = 2; pl->nkw = 2; }  // (4 fragments per wave spill at this width)
     else if (d <= 80) { pl->ks = 3; pl->df = 5; pl->rb = 2; pl->rb_dq = 2; pl->nkw = 2; }
     else if (d <= 96) { pl->ks = 3; pl->df = 6; pl->rb = 2; pl->rb_dq = 2; pl->nkw = 2; }
     else if (d <= 128) { pl->ks = 4; pl->df = 8; pl->rb = 2; pl->rb_dq = 1; pl->nkw = 1; }
     else { pl->ks = 5; pl->df = 10; pl->rb = 1; pl->rb_dq = 1; pl->nkw = 1; }
+    static const int nkw_env = [] { const char* e = getenv("FLASH_NKW"); return e ? atoi(e) : 0; }();  // tools/flash_check.py
+    if (nkw_env == 2 && pl->nkw == 4) pl->nkw = 2;
     static const int rb_env = [] { const char* e = getenv("FLASH_RB"); return e ? atoi(e) : 0; }();
     if (rb_env == 2 && pl->rb == 4) pl->rb = 2;  // tuning knob for tools/flash_check.py
     return true;
@@ -844,7 +846,7 @@ int launch_flash_bwd(const FlashBwdArgs& a, hipStream_t stream) {
     }
     {
         constexpr int lds = flash_dkdv_lds<KS, DF>();
-        auto kern = attn_flash_dkdv_kernel<T, KS, DF, NKW, (KS >= 3)>;
+        auto kern = attn_flash_dkdv_kernel<T, KS, DF, NKW, (KS >= 3 || NKW <= 2)>;
         if (lds > 48 * 1024) {
             static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -864,7 +866,7 @@ template <typename T>
 int dispatch_flash_bwd(const FlashBwdArgs& a, const FlashPlan& pl, hipStream_t stream) {
 #define FLASH_BCASE(KS_, DF_, RBQ_, NKW_) \
     if (pl.ks == KS_ && pl.df == DF_ && pl.nkw == NKW_) return launch_flash_bwd<T, KS_, DF_, RBQ_, NKW_>(a, stream);
-    FLASH_BCASE(2, 3, 2, 4) FLASH_BCASE(2, 4, 2, 4) FLASH_BCASE(3, 5, 2, 2) FLASH_BCASE(3, 6, 2, 2)
+    FLASH_BCASE(2, 3, 2, 4) FLASH_BCASE(2, 4, 2, 4) FLASH_BCASE(2, 3, 2, 2) FLASH_BCASE(2, 4, 2, 2) FLASH_BCASE(3, 5, 2, 2) FLASH_BCASE(3, 6, 2, 2)
     FLASH_BCASE(4, 8, 1, 1) FLASH_BCASE(5, 10, 1, 1)
 #undef FLASH_BCASE
     return LORA_E_BADARG;
