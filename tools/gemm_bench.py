@@ -8,6 +8,7 @@ dev = "cuda"
 SHAPES = [(16384,320,320),(16384,320,2560),(16384,1280,320),(4096,640,640),(4096,640,5120),(4096,2560,640),(1024,1280,1280),(1024,1280,10240),(1024,5120,1280),(256,1280,1280),(256,1280,10240),(308,768,320),(308,768,1280)]
 COLD = "--cold" in sys.argv or "--cold-read" in sys.argv  # in-model conditions: weights come from HBM (a 600 MB write evicts L2 + Infinity Cache), the row operand was just written
 _flush = None
+PREFETCH = [None]
 def run(fn, iters=20, warm=None):
     global _flush
     iters = int(os.environ.get("GB_ITERS", iters))
@@ -18,6 +19,8 @@ def run(fn, iters=20, warm=None):
             if "--cold-read" in sys.argv: _flush.view(torch.float32).sum()  # evict with CLEAN lines (no write-backs competing with the kernel)
             else: _flush.zero_()
             if warm is not None: warm.mul_(1.0)
+            if "--prefetch" in sys.argv and PREFETCH[0] is not None:  # premise test: the weight read once (→ Infinity Cache) before the launch
+                PREFETCH[0].view(torch.float32).view(-1)[::32].sum()
             inner()
     for _ in range(3): fn()
     torch.cuda.synchronize()
@@ -39,7 +42,9 @@ def per_shape():
         a = torch.randn(4,K,device=dev)/4; b = torch.randn(N,4,device=dev)*0.05; dy = torch.randn(M,N,device=dev).to(dtype)
         y, t = nat.lora_linear_fwd(x,w,None,a,b,1.0); dx,u = nat.lora_linear_bwd_input(dy,wt,a,b,1.0,True)
         ga = torch.zeros(4,K,device=dev); gb = torch.zeros(N,4,device=dev)
+        PREFETCH[0] = w
         tf, _, kf = run(lambda: nat.lora_linear_fwd(x,w,None,a,b,1.0), warm=x)
+        PREFETCH[0] = wt
         tb, _, kb = run(lambda: nat.lora_linear_bwd_input(dy,wt,a,b,1.0,True), warm=dy)
         fl = 2.0*M*K*N; by = 2.0*(M*K+N*K+M*N)
         line = f"{M:6d}x{K:5d}x{N:6d} fwd {tf:7.1f}us {fl/tf/1e6:6.0f}TF {by/tf/1e3:6.0f}GB/s [{kf[0][18:28]}] | bwd {tb:7.1f}us {fl/tb/1e6:6.0f}TF [{kb[0][18:28]}] {kb[-1] if len(kb) > 1 else ''}"
