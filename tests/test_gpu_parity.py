@@ -70,6 +70,9 @@ SD_SHAPES = [  # (M, K, N, bias): the distinct LoRA GEMMs of SD1.5 at 512² / B=
     (308, 768, 768, True), (9216, 320, 320, False), (2304, 640, 640, True), (2304, 1024, 640, False),
     (576, 1280, 1280, True), (256, 1280, 1280, False), (1024, 10240, 1280, False), (333, 320, 960, False),
     (2304, 1024, 1280, False), (77, 1024, 1280, False),
+    # every tile class of the ring kernel: 64×128 two-stage (128..255-tile grids), 128×160 with a ragged last row tile and
+    # six column tiles, 128×128 at >= 256 tiles
+    (4096, 640, 640, True), (8200, 320, 960, False), (4096, 320, 1280, True),
 ]
 
 
