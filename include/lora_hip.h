@@ -351,8 +351,9 @@ int attn_ctx_bwd(const void* Q, const void* K, const void* V, const void* dO, vo
  *   attn_flash_fwd                : O and LSE [B, H, Tq] fp32 = log2-sum-exp2 of the scaled scores (saved for backward;
  *                                   may be NULL when no backward follows).
  *   attn_flash_bwd_workspace_bytes: B·H·Tq·4 (the softmax correction Δ = Σ dO·O per query row).
- *   attn_flash_bwd                : dQ, dK, dV from Q, K, V, O, dO, LSE.  Three launches (Δ; key-owned dK/dV; query-owned
- *                                   dQ), every output element written by one workgroup: deterministic, no atomics.
+ *   attn_flash_bwd                : dQ, dK, dV from Q, K, V, O, dO, LSE.  Two launches (query-owned dQ, which also fills the
+ *                                   workspace with Δ; key-owned dK/dV), every output element written by one workgroup:
+ *                                   deterministic, no atomics.
  */
 int attn_flash_supported(int B, int Tq, int Tk, int H, int d, int dtype);
 /* _strided forms: Q, K, V share the row stride ldq and dQ, dK, dV the row stride ld_dq (elements): the three column
