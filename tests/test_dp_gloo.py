@@ -1,4 +1,4 @@
-"""World-size-2 data-parallel exchange on CPU (gloo): N ranks × batch B must equal 1 rank × batch N·B.
+"""World-size-2 and -4 data-parallel exchange on CPU (gloo): N ranks × batch B must equal 1 rank × batch N·B.
 
 The gradients are produced by the oracle here (the HIP kernels need a GPU); what is under test is the product's
 exchange logic — SlabExchange: two buckets, SUM all-reduce, 1/world folded into the optimizer multiplier."""
@@ -59,15 +59,21 @@ def _worker(rank, world, port, out):
     ex2 = SlabExchange(grads2, n)
     ex2.arm()
     ex2.finish()
-    assert torch.equal(grads2, grads)
+    if world == 2:
+        assert torch.equal(grads2, grads)  # two addends: the order cannot matter
+    else:  # the collective library sums a bucket in an order that depends on its size: equal up to fp32 summation order
+        assert ((grads2 - grads).norm() / grads.norm()).item() < 1e-6
     if rank == 0:
         out.put(mean)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_exchange_equals_single_rank_double_batch():
-    world = 2
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_n_rank_exchange_equals_single_rank_n_fold_batch(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -78,6 +84,6 @@ def test_two_rank_exchange_equals_single_rank_double_batch():
     for p in procs:
         p.join(timeout=240)
         assert p.exitcode == 0
-    single = _local_grads(0, 1, 4)  # one rank, batch 4 = concatenation of both shards
+    single = _local_grads(0, 1, 2 * world)  # one rank, batch 2·world = concatenation of all shards
     err = ((mean - single).norm() / single.norm()).item()
     assert err < 1e-5, err
