@@ -13,7 +13,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "lib
 _lib = None
 _lock = threading.Lock()
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 PROF_KINDS = 10
 
 _DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
@@ -76,6 +76,7 @@ SIGNATURES = {
     "ddpm_add_noise": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
     "ddpm_noise_prologue": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, ctypes.c_uint64, ctypes.c_uint64,
                                    _i32, _i32, _vp]),
+    "geglu_linear_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "geglu_gate_fwd": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "geglu_gate_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "attn_split_heads": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -520,6 +521,28 @@ def geglu_gate_bwd(y2, dout2):
     dy = torch.empty_like(y2)
     _check(lib().geglu_gate_bwd(_ptr(y2), _ptr(dout2), _ptr(dy), M, C2 // 2, dtype_code(y2.dtype), _stream(y2)),
            "geglu_gate_bwd")
+    return dy
+
+
+_zero_factors = {}
+
+
+def geglu_linear_bwd(dz2, w2t, y2):
+    """Backward of `z = (h·gelu(g)) @ W2ᵀ + b2` w.r.t. y = [h | g] in ONE launch (the gate's backward rides in the epilogue
+    of dout = dz·W2): dz2 [M,Nz], w2t = W2ᵀ [F,Nz], y2 [M,2F] → dY [M,2F]; None when the library has no fused kernel."""
+    _require_device(dz2, w2t, y2)
+    M, Nz = dz2.shape
+    F = w2t.shape[0]
+    key = (dz2.device, dz2.dtype)
+    z = _zero_factors.get(key)
+    if z is None or z.numel() < 16 * max(Nz, F):
+        z = _zero_factors[key] = torch.zeros(16 * max(Nz, F, 10240), dtype=dz2.dtype, device=dz2.device)
+    dy = torch.empty_like(y2)
+    st = lib().geglu_linear_bwd(_ptr(dz2), _ptr(w2t), _ptr(y2), _ptr(dy), _ptr(z), M, Nz, F, dtype_code(dz2.dtype) if dz2.dtype != torch.float32 else 0,
+                                _stream(dz2))
+    if st == -5:
+        return None
+    _check(st, "geglu_linear_bwd")
     return dy
 
 

@@ -137,10 +137,61 @@ def _hip_geglu_forward(self, hidden_states, *args, **kwargs):
     return geglu_gate(proj(hidden_states))
 
 
+def _plain_lora_linear(m) -> bool:
+    from .core import LoraInjectedLinear
+
+    return (type(m) is LoraInjectedLinear and "forward" not in m.__dict__ and not m._forward_hooks
+            and not m._forward_pre_hooks)
+
+
+def _is_geglu_feed_forward(m: nn.Module) -> bool:
+    """diffusers FeedForward with a GEGLU activation: `net = [GEGLU(proj), Dropout, Linear]`, run as `for f in net: x = f(x)`."""
+    net = getattr(m, "net", None)
+    if m.__class__.__name__ != "FeedForward" or net is None or len(net) != 3:
+        return False
+    return (net[0].__class__.__name__ == "GEGLU" and hasattr(net[0], "proj") and isinstance(net[1], nn.Dropout)
+            and type(net[2]) is nn.Linear)
+
+
+def _hip_feed_forward(self, hidden_states, *args, **kwargs):
+    """FeedForward.forward with the gate inside GEMM epilogues in BOTH directions (ops.feed_forward_geglu): forward in the
+    `proj` LoRA launch, backward in the launch that computes the second linear layer's input gradient.  Anything outside
+    that envelope — extra arguments, active dropout, a `proj` that is not a plain LoraInjectedLinear, a second layer that is
+    trainable or hooked, no gradient wanted — takes the module's own forward (whose GEGLU keeps its forward-only fusion)."""
+    geglu, drop, lin2 = self.net[0], self.net[1], self.net[2]
+    ok = (not args and not kwargs and hidden_states.is_cuda and torch.is_grad_enabled()
+          and not (drop.training and drop.p > 0) and _plain_lora_linear(geglu.proj)
+          and "forward" not in lin2.__dict__ and not lin2._forward_hooks and not lin2._forward_pre_hooks
+          and not lin2.weight.requires_grad and (lin2.bias is None or not lin2.bias.requires_grad)
+          and (hidden_states.requires_grad or geglu.proj.lora_up.weight.requires_grad))
+    if not ok:
+        return self.__dict__[_ORIG](hidden_states, *args, **kwargs)
+    from .ops import feed_forward_geglu
+
+    return feed_forward_geglu(geglu.proj, lin2, hidden_states)
+
+
 def set_use_hip_geglu(module: nn.Module, valid: bool = True) -> int:
     """Install / remove the fused GEGLU gate on every module whose class is named "GEGLU" (the LoRA target class of
-    lora_diffusion/lora.py:53) and that has a `proj` linear.  The reference has no switch for this op; a trainer that
-    wants it adds one line next to its `--use_xformers` line.  Returns the number of modules touched."""
+    lora_diffusion/lora.py:53) and that has a `proj` linear — and, on every "FeedForward" module built around such a GEGLU,
+    the forward that also folds the gate's BACKWARD into the following linear layer's backward GEMM.  The reference has no
+    switch for this op; a trainer that wants it adds one line next to its `--use_xformers` line.  Returns the number of GEGLU
+    modules touched."""
+    import os
+
+    ff_fusion = os.environ.get("DFA_NO_FF_FUSION", "0") != "1"  # dev knob (tools/ab_env.sh): forward-only gate fusion
+    for m in module.modules():
+        if not _is_geglu_feed_forward(m):
+            continue
+        has = _ORIG in m.__dict__
+        if valid and not has and ff_fusion:
+            m.__dict__[_ORIG] = m.forward
+            m.forward = functools.partial(_hip_feed_forward, m)
+        elif not valid and has:
+            orig = m.__dict__.pop(_ORIG)
+            del m.forward
+            if getattr(orig, "__func__", None) is not type(m).forward:
+                m.forward = orig
     touched = 0
     for m in module.modules():
         if m.__class__.__name__ != "GEGLU" or not hasattr(m, "proj"):

@@ -136,7 +136,7 @@ template <int BM, int BN, typename T, bool MAIN, int STG, int NW, int WM> conste
 
 // STG: LDS ring depth of the DMA pipeline (2 or 3); 0 selects the register-staged fallback loop.
 // NW waves as WM row waves × NW/WM column waves; every wave owns a (BM/WM) × (BN·WM/NW) piece of the tile.
-template <typename T, int BM, int BN, bool MAIN, int STG, int NW, int WM, bool GATE = false>
+template <typename T, int BM, int BN, bool MAIN, int STG, int NW, int WM, int GATE = 0>  // GATE: 0 none, 1 GEGLU forward, 2 GEGLU backward
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(GemmParams p) {  // 4-wave tiles: two per CU
     constexpr bool PIPE = STG > 0;
     constexpr int kStages = PIPE ? STG : 1;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
     // tile-local column → column of C / row of Bm.  GATE: the first half of the tile is a run of h columns, the second
     // half the run of g columns that gates them (both halves are whole: gateF % (BN/2) == 0).
     auto gcol = [&](int c) {
-        if constexpr (GATE) return c < BN / 2 ? tn * (BN / 2) + c : p.gateF + tn * (BN / 2) + (c - BN / 2);
+        if constexpr (GATE == 1) return c < BN / 2 ? tn * (BN / 2) + c : p.gateF + tn * (BN / 2) + (c - BN / 2);
         else return n0 + c;
     };
 
@@ -707,7 +707,54 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
             }
             __syncthreads();
             STAMP(7);
-            if constexpr (GATE) {
+            if constexpr (GATE == 2) {
+                // GEGLU BACKWARD in the epilogue of the GEMM that produces its incoming gradient: this launch is
+                //     dout[M,F] = dZ[M,Nz]·W2        (backward-input of the linear layer behind the gate: ff.net.2)
+                // and the tile in LDS is dout, rounded to the storage type exactly as the separate tensor would be.  Thread =
+                // (row, chunk): it loads the h and g chunks of Y = [h | g] (p.C2, read-only) and writes the two halves of
+                //     dY[:, :F] = dout·gelu(g),   dY[:, F:] = dout·h·gelu'(g)        (p.C)
+                // — the arithmetic of geglu_bwd_kernel on the same values; dout itself never goes to memory.
+                static_assert(FASTC && EP == 1, "the gate epilogue reads the whole C tile from one ring buffer");
+                constexpr int NST = ROWS * CPR / NT;
+                static_assert(NST % 2 == 0, "two register batches");
+                const T* Yg = static_cast<const T*>(p.C2);
+                const int F = p.gateF;
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    Chunk<T> dv[NST / 2], hv[NST / 2], gv[NST / 2];
+#pragma unroll
+                    for (int i = 0; i < NST / 2; ++i) {
+                        const int idx = tid + (hb * (NST / 2) + i) * NT;
+                        const int row = idx / CPR, ch = idx - row * CPR;
+                        int64_t m = m0 + row;
+                        if (m > p.M - 1) m = p.M - 1;  // rows past the end: loaded from a valid row, never stored
+                        const T* yrow = Yg + m * (2 * (int64_t)F) + n0 + ch * VEC;
+                        hv[i] = *reinterpret_cast<const Chunk<T>*>(yrow);
+                        gv[i] = *reinterpret_cast<const Chunk<T>*>(yrow + F);
+                        dv[i] = *reinterpret_cast<const Chunk<T>*>(sC + row * SC_STRIDE + ch * 16);
+                    }
+#pragma unroll
+                    for (int i = 0; i < NST / 2; ++i) {
+                        const int idx = tid + (hb * (NST / 2) + i) * NT;
+                        const int row = idx / CPR, ch = idx - row * CPR;
+                        const int64_t m = m0 + row;
+                        Chunk<T> dh, dg;
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            const float g = to_f32<T>(gv[i].v[e]), d = to_f32<T>(dv[i].v[e]);
+                            dh.v[e] = from_f32<T>(d * gelu_f<T>(g));
+                            dg.v[e] = from_f32<T>(d * to_f32<T>(hv[i].v[e]) * gelu_grad_f<T>(g));
+                        }
+                        if (m < p.M) {
+                            T* drow = Cg + m * (2 * (int64_t)F) + n0 + ch * VEC;
+                            *reinterpret_cast<Chunk<T>*>(drow) = dh;
+                            *reinterpret_cast<Chunk<T>*>(drow + F) = dg;
+                        }
+                    }
+                }
+                continue;
+            }
+            if constexpr (GATE == 1) {
                 // thread = (row, 16-B chunk of the h half) and the chunk of g behind it: y leaves as it is (when a backward
                 // pass will want it), out = h·gelu(g) from the SAME rounded values the separate gate kernel would read
                 static_assert(FASTC && EP == 1, "the gate epilogue reads the whole C tile from one ring buffer");
@@ -1036,7 +1083,24 @@ int launch_gate(GemmParams p, hipStream_t stream) {
     p.tiles_n = p.gateF / (BN / 2);
     p.col_major = (int64_t)p.Nc > p.M ? 1 : 0;
     constexpr int lds = gemm_lds_bytes<BM, BN, T, true, 2, 4, 2>();
-    auto kern = lora_gemm_kernel<T, BM, BN, true, 2, 4, 2, true>;
+    auto kern = lora_gemm_kernel<T, BM, BN, true, 2, 4, 2, 1>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (attr != hipSuccess) return LORA_E_LAUNCH;
+    LORA_LAUNCH(PK_GEMM_128x128, kern, dim3(p.tiles_m * p.tiles_n), dim3(256), lds, stream, p);
+    LORA_LAUNCH_CHECK();
+    return LORA_OK;
+}
+
+// GEGLU backward in the epilogue of dout = dZ·W2: 128×128 tiles over [M, F].
+template <typename T>
+int launch_gate_bwd(GemmParams p, hipStream_t stream) {
+    constexpr int BM = 128, BN = 128;
+    p.tiles_m = (int)((p.M + BM - 1) / BM);
+    p.tiles_n = p.Nc / BN;
+    p.col_major = (int64_t)p.Nc > p.M ? 1 : 0;
+    constexpr int lds = gemm_lds_bytes<BM, BN, T, true, 2, 4, 2>();
+    auto kern = lora_gemm_kernel<T, BM, BN, true, 2, 4, 2, 2>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr != hipSuccess) return LORA_E_LAUNCH;
@@ -1357,6 +1421,26 @@ extern "C" int lora_linear_geglu_fwd(const void* X, const void* W, const void* b
                   2.0 * M * K * N + 2.0 * M * r * (double)(K + N));
     hipStream_t s = static_cast<hipStream_t>(stream);
     return dtype == LORA_F16 ? launch_gate<half_t>(p, s) : launch_gate<bf16_t>(p, s);
+}
+
+extern "C" int geglu_linear_bwd(const void* dZ, const void* W2t, const void* Y, void* dY, const void* zeros, int64_t M,
+                                int Nz, int F, int dtype, void* stream) {
+    if (M < 0 || Nz <= 0 || F <= 0) return LORA_E_BADARG;
+    if (dtype != LORA_F32 && dtype != LORA_F16 && dtype != LORA_BF16) return LORA_E_BADARG;
+    if (M == 0) return LORA_OK;
+    if (!dZ || !W2t || !Y || !dY || !zeros) return LORA_E_BADARG;
+    if (dtype == LORA_F32 || (Nz % 64) != 0 || (F % 128) != 0) return LORA_E_UNSUPPORTED;
+    if (!aligned16(dZ) || !aligned16(W2t) || !aligned16(Y) || !aligned16(dY) || !aligned16(zeros)) return LORA_E_UNSUPPORTED;
+    GemmParams p{};
+    p.Am = dZ; p.Bm = W2t; p.bias = nullptr;
+    p.Fp = zeros;  // no rank-r term in this launch: a zero factor tile [16, Nz] and a zero epilogue factor [F, 16]
+    p.Qp = zeros;
+    p.C = dY; p.C2 = const_cast<void*>(Y); p.gateF = F; p.P = nullptr;
+    p.M = M; p.Kc = Nz; p.Nc = F; p.r = 1; p.scale = 0.f; p.lda = Nz;
+    const double e = 2.0;
+    ProfWork work(e * ((double)M * Nz + (double)F * Nz + 4.0 * (double)M * F), 2.0 * M * (double)Nz * F);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dtype == LORA_F16 ? launch_gate_bwd<half_t>(p, s) : launch_gate_bwd<bf16_t>(p, s);
 }
 
 extern "C" int64_t lora_gemm_workspace_bytes(int64_t M, int Kc, int Nc, int dtype) {

@@ -183,6 +183,104 @@ class _LoraGegluFn(torch.autograd.Function):
         return (*_lora_backward(ctx, x2, a, b, t, dy2), None, None, None, None, None, None)
 
 
+class _LoraProjGatedFn(torch.autograd.Function):
+    """The `proj` LoraInjectedLinear of a GEGLU block for a caller that also owns what follows the gate (feed_forward below):
+    ONE launch produces y = [h | g] — the differentiable output, whose gradient is the usual LoRA backward — and the gated
+    activation h·gelu(g) as a non-differentiable by-product."""
+
+    @staticmethod
+    def forward(ctx, x, down, up, w, wt, bias, scale, grad_sink, packed):
+        K = w.shape[1]
+        x2 = x.reshape(-1, K)
+        if x2.dtype != w.dtype:
+            x2 = x2.to(w.dtype)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        a = _as_f32(down)
+        b = _as_f32(up)
+        packs = packed if packed is not None else nat.lora_pack_factors(a, b, w.dtype)
+        res = nat.lora_linear_geglu_fwd(x2, w, bias, a.shape[0], scale, packs, True)
+        if res is None:
+            y2, t = nat.lora_linear_fwd(x2, w, bias, a, b, scale, packs)
+            out = nat.geglu_gate_fwd(y2)
+        else:
+            out, y2, t = res
+        ctx.save_for_backward(x2, a, b, t)
+        ctx.packs = packs
+        ctx.wt = wt
+        ctx.scale = float(scale)
+        ctx.x_shape = x.shape
+        ctx.x_dtype = x.dtype
+        ctx.factor_dtypes = (down.dtype, up.dtype)
+        ctx.grad_sink = grad_sink
+        N = w.shape[0]
+        out = out.view(*x.shape[:-1], N // 2)
+        ctx.mark_non_differentiable(out)
+        return y2.view(*x.shape[:-1], N), out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy, _dout):
+        x2, a, b, t = ctx.saved_tensors
+        dy2 = dy.reshape(-1, b.shape[0])
+        if dy2.dtype != x2.dtype:
+            dy2 = dy2.to(x2.dtype)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        return (*_lora_backward(ctx, x2, a, b, t, dy2), None, None, None, None, None, None)
+
+
+class _GatedLinearFn(torch.autograd.Function):
+    """z = gated @ W2ᵀ + b2 with gated = h·gelu(g) of y = [h | g] (diffusers FeedForward: net[2](net[0](x))), W2 / b2 frozen.
+    The graph edge goes to y, not to `gated`: backward is ONE launch, dY = gate-backward(dz·W2, y) (`geglu_linear_bwd`) —
+    the gate's backward sits in the epilogue of the linear layer's backward-input GEMM."""
+
+    @staticmethod
+    def forward(ctx, y, gated, w2, w2t, b2):
+        ctx.save_for_backward(y, w2, w2t)
+        return torch.nn.functional.linear(gated, w2, b2)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz):
+        y, w2, w2t = ctx.saved_tensors
+        y2 = y.reshape(-1, y.shape[-1])
+        dz2 = dz.reshape(-1, dz.shape[-1])
+        if dz2.dtype != y2.dtype:
+            dz2 = dz2.to(y2.dtype)
+        if not dz2.is_contiguous():
+            dz2 = dz2.contiguous()
+        dy = nat.geglu_linear_bwd(dz2, w2t, y2)
+        if dy is None:  # no fused kernel for this shape / dtype: the two steps it stands for
+            dy = nat.geglu_gate_bwd(y2, dz2 @ w2)
+        return dy.view(y.shape), None, None, None, None
+
+
+def _frozen_linear(lin, cdtype: torch.dtype):
+    """(W, Wᵀ, bias) of a frozen nn.Linear in `cdtype`, cached on the module like _frozen_operands."""
+    w, b = lin.weight, lin.bias
+    key = (w.data_ptr(), w._version, w.dtype, w.device, cdtype, None if b is None else (b.data_ptr(), b._version))
+    cache = lin.__dict__.get("_dfa_cache")
+    if cache is None or cache["key"] != key:
+        wd = w.detach()
+        if not wd.is_contiguous():
+            wd = wd.contiguous()
+        wc = wd if wd.dtype == cdtype else nat.lora_cast_matrix(wd, cdtype, False)
+        cache = {"key": key, "w": wc, "wt": nat.lora_cast_matrix(wc, cdtype, True),
+                 "bias": None if b is None else b.detach().to(cdtype).contiguous()}
+        lin.__dict__["_dfa_cache"] = cache
+    return cache["w"], cache["wt"], cache["bias"]
+
+
+def feed_forward_geglu(proj_module, lin2, x: torch.Tensor) -> torch.Tensor:
+    """diffusers FeedForward with a GEGLU activation — `net[2](net[0](x))`, net[0] = GEGLU(proj), net[2] = frozen Linear — with
+    BOTH halves of the gate inside GEMM epilogues: forward in the `proj` launch, backward in the launch that computes net[2]'s
+    input gradient.  `proj_module` is the LoraInjectedLinear, `lin2` the nn.Linear."""
+    y, gated = lora_linear(proj_module, x, gate="pair")
+    w2, w2t, b2 = _frozen_linear(lin2, y.dtype)
+    return _GatedLinearFn.apply(y, gated, w2, w2t, b2)
+
+
 def lora_linear(module, x: torch.Tensor, gate: bool = False) -> torch.Tensor:
     """Fused LoraInjectedLinear forward (lora_diffusion/lora.py:49-50) on the HIP device; `gate`: see lora_linear_geglu."""
     global _warned_trainable_base
@@ -206,7 +304,7 @@ def lora_linear(module, x: torch.Tensor, gate: bool = False) -> torch.Tensor:
     packed = module.__dict__.get("_dfa_packed")
     if packed is not None and packed[0].dtype != cdtype:
         packed = None
-    fn = _LoraGegluFn if gate else _LoraLinearFn
+    fn = _LoraProjGatedFn if gate == "pair" else (_LoraGegluFn if gate else _LoraLinearFn)
     return fn.apply(x, down, up, w, wt, bias, float(module.scale), sink, packed)
 
 

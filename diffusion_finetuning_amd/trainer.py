@@ -480,8 +480,14 @@ class LoraTrainer:
         """Everything a recorded step has baked in besides the shapes: scalars passed as kernel arguments and the
         addresses / versions of the frozen operands the caches hand to the kernels."""
         layers = self.slab.layers
+        # (the second linear layer of a hooked FeedForward hands cached W2 / W2ᵀ copies to the fused gate backward as well)
+        ffs = self.__dict__.get("_ff_modules")
+        if ffs is None:  # the module tree is walked once; the per-step check touches the 16 feed-forward blocks only
+            ffs = self._ff_modules = [m for m in self.unet.modules()
+                                      if m.__class__.__name__ == "FeedForward" and hasattr(m, "net") and len(m.net) == 3]
+        ff2 = tuple((m.net[2].weight.data_ptr(), m.net[2].weight._version) for m in ffs if "forward" in m.__dict__)
         return (self.loss_scale, self.v_prediction, tuple(float(l.scale) for l in layers),
-                tuple((l.linear.weight.data_ptr(), l.linear.weight._version) for l in layers))
+                tuple((l.linear.weight.data_ptr(), l.linear.weight._version) for l in layers), ff2)
 
     # -- one step ---------------------------------------------------------------------------------
     def step(self, latents, noise, timesteps, encoder_hidden_states, *, with_prior_preservation=False,

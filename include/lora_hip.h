@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LORA_HIP_ABI_VERSION 3
+#define LORA_HIP_ABI_VERSION 4
 
 enum lora_dtype { LORA_F32 = 0, LORA_F16 = 1, LORA_BF16 = 2 };
 
@@ -100,6 +100,20 @@ int lora_linear_fwd(const void* X, const void* W, const void* bias /* nullable *
 int lora_linear_geglu_fwd(const void* X, const void* W, const void* bias /* nullable */, const void* Apack,
                           const void* Bpack, void* Y /* nullable */, void* Out, float* T_out, int64_t M, int K, int N,
                           int r, float scale, int dtype, void* stream);
+
+/*
+ * Backward of the same gate, in the epilogue of the GEMM that produces its incoming gradient.  In a transformer block the
+ * gated activation feeds a frozen linear layer (diffusers FeedForward: net = [GEGLU, Dropout, Linear]); autograd of
+ *     z = (hidden * gelu(gate)) @ W2ᵀ + b2 ,   [hidden | gate] = Y = proj(x)      (proj: the LoraInjectedLinear above)
+ * needs  dout = dZ·W2  [M,F]  and then  dY[:, :F] = dout·gelu(gate),  dY[:, F:] = dout·hidden·gelu'(gate).
+ * geglu_linear_bwd does both in ONE launch: dout never goes to memory (it is rounded to `dtype` in the tile, exactly as the
+ * separate tensor would be) and dY [M,2F] is what lora_linear_bwd_input / lora_grad_batched of `proj` consume.
+ * W2t = W2ᵀ [F, Nz] row-major in `dtype` (lora_cast_matrix, transpose); zeros: at least 32·max(Nz, F) zero bytes (the launch
+ * has no rank-r term).  16-bit dtypes, Nz % 64 == 0, F % 128 == 0; otherwise LORA_E_UNSUPPORTED (caller: a GEMM of its own
+ * followed by geglu_gate_bwd).
+ */
+int geglu_linear_bwd(const void* dZ, const void* W2t, const void* Y, void* dY, const void* zeros, int64_t M, int Nz,
+                     int F, int dtype, void* stream);
 
 /*
  * Backward w.r.t. the input — autograd of lora.py:49-50 as driven by

@@ -165,3 +165,118 @@ def test_geglu_hook_routes_proj_through_the_gated_kernel_and_backpropagates(clos
     assert torch.equal(out_ng, out)
     # the switch comes off again
     assert set_use_hip_geglu(mod, False) == 1
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,Nz,F", [(1024, 320, 1280), (300, 640, 2560), (256, 1280, 5120), (129, 64, 128)])
+def test_gate_backward_in_the_epilogue_of_the_following_linear_layers_backward(close, dtype, M, Nz, F):
+    """`geglu_linear_bwd`: dY = gate-backward(dZ·W2, Y) in one launch.  Bit-identical to the library's own two steps (the same
+    GEMM kernel without a gate, then geglu_gate_bwd on the rounded dout), and close to float64 autograd of
+    z = (h·gelu(g)) @ W2ᵀ."""
+    g = torch.Generator().manual_seed(M + F)
+    y = torch.randn(M, 2 * F, generator=g).to(dtype)
+    w2 = (torch.randn(Nz, F, generator=g) / F ** 0.5).to(dtype)
+    dz = torch.randn(M, Nz, generator=g).to(dtype)
+    yd, w2d, dzd = y.to(DEV), w2.to(DEV), dz.to(DEV)
+    w2t = nat.lora_cast_matrix(w2d, dtype, True)  # [F, Nz]
+    dy = nat.geglu_linear_bwd(dzd, w2t, yd)
+    assert dy is not None and dy.shape == (M, 2 * F)
+    # the two steps it stands for, on the same kernel: dout = dZ·W2 through lora_gemm_packed with zero factors, then the gate
+    zf = torch.zeros(16 * max(Nz, F), dtype=dtype, device=DEV)
+    dout = torch.empty(M, F, dtype=dtype, device=DEV)
+    nat.lora_gemm_packed(dzd, Nz, w2t, None, zf, zf, None, None, 0, dout, None, M, Nz, F, 1, 0.0)
+    assert torch.equal(dy, nat.geglu_gate_bwd(yd, dout))
+    # float64 autograd of the reference composite
+    yr = y.double().requires_grad_(True)
+    h, gt = yr.chunk(2, dim=-1)
+    ((h * torch.nn.functional.gelu(gt)) @ w2.double().t()).backward(dz.double())
+    close(dy, yr.grad, 3e-3 if dtype == torch.float16 else 2e-2, "dY")
+
+
+def test_gate_backward_shapes_without_a_fused_kernel_are_reported():
+    for (M, Nz, F, dtype) in [(64, 64, 96, torch.float16), (64, 72, 128, torch.float16), (64, 64, 128, torch.float32)]:
+        y = torch.randn(M, 2 * F, device=DEV).to(dtype)
+        w2t = torch.randn(F, Nz, device=DEV).to(dtype)
+        dz = torch.randn(M, Nz, device=DEV).to(dtype)
+        assert nat.geglu_linear_bwd(dz, w2t, y) is None
+
+
+class _FeedForward(torch.nn.Module):  # diffusers FeedForward layout: net = [GEGLU, Dropout, Linear]
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        self.net = torch.nn.ModuleList([_GEGLU(dim, dim * mult), torch.nn.Dropout(0.0), torch.nn.Linear(dim * mult, dim)])
+
+    def forward(self, x):
+        for m in self.net:
+            x = m(x)
+        return x
+
+
+_FeedForward.__name__ = "FeedForward"
+
+
+@pytest.mark.parametrize("mode", ["half_model", "autocast_fp16", "fp32"])
+def test_feed_forward_hook_folds_both_halves_of_the_gate(close, relerr, monkeypatch, mode):
+    """`set_use_hip_geglu` on a FeedForward(GEGLU) block: forward = the gated `proj` launch + the stock second linear layer,
+    backward = `geglu_linear_bwd` (no gate kernel at all) + the LoRA backward; against float64 autograd of the reference
+    composite.  fp32 has no fused kernels and takes the unfused steps with the same results; without gradients, or with active
+    dropout, the module's own forward runs."""
+    from diffusion_finetuning_amd.attention import set_use_hip_geglu
+
+    torch.manual_seed(9)
+    K, M = 320, 515
+    ff = _FeedForward(K)
+    ff.requires_grad_(False)
+    dfa.inject_trainable_lora(ff, target_replace_module={"GEGLU"}, r=4)
+    proj = ff.net[0].proj
+    with torch.no_grad():
+        proj.lora_up.weight.normal_(0, 0.05)
+    x = torch.randn(2, M, K)
+    dz = torch.randn(2, M, K)
+    cd = torch.float32 if mode == "fp32" else torch.float16
+    xr = x.to(cd).double().requires_grad_(True)
+    A = proj.lora_down.weight.detach().double().requires_grad_(True)
+    Bm = proj.lora_up.weight.detach().double().requires_grad_(True)
+    W1, b1 = proj.linear.weight.detach().to(cd).double(), proj.linear.bias.detach().to(cd).double()
+    W2, b2 = ff.net[2].weight.detach().to(cd).double(), ff.net[2].bias.detach().to(cd).double()
+    yr = xr @ W1.t() + b1 + (xr @ A.t()) @ Bm.t()
+    hr, gr = yr.chunk(2, dim=-1)
+    zr = (hr * torch.nn.functional.gelu(gr)) @ W2.t() + b2
+    zr.backward(dz.to(cd).double())
+
+    ff = ff.to(DEV)
+    if mode == "half_model":
+        ff = ff.half()
+    assert set_use_hip_geglu(ff) == 1 and "forward" in ff.__dict__
+    calls = {"gate_bwd": 0, "fused_bwd": 0}
+    real_gate, real_fused = nat.geglu_gate_bwd, nat.geglu_linear_bwd
+
+    def count(name, fn):
+        def wrapped(*a, **k):
+            res = fn(*a, **k)
+            calls[name] += res is not None
+            return res
+        return wrapped
+
+    monkeypatch.setattr(nat, "geglu_gate_bwd", count("gate_bwd", real_gate))
+    monkeypatch.setattr(nat, "geglu_linear_bwd", count("fused_bwd", real_fused))
+    xg = x.to(DEV).to(torch.float16 if mode == "half_model" else torch.float32).requires_grad_(True)
+    if mode == "autocast_fp16":
+        with torch.autocast("cuda", dtype=torch.float16):
+            z = ff(xg)
+    else:
+        z = ff(xg)
+    z.backward(dz.to(DEV).to(z.dtype))
+    assert calls == ({"gate_bwd": 1, "fused_bwd": 0} if mode == "fp32" else {"gate_bwd": 0, "fused_bwd": 1}), calls
+    tol = 2e-5 if mode == "fp32" else 4e-3
+    close(z, zr.detach(), tol, "z")
+    close(xg.grad, xr.grad, tol, "dx")
+    assert relerr(proj.lora_down.weight.grad, A.grad) < tol and relerr(proj.lora_up.weight.grad, Bm.grad) < tol
+    with torch.no_grad():  # no gradient wanted: the module's own forward (its GEGLU keeps the forward-only fusion)
+        if mode == "autocast_fp16":
+            with torch.autocast("cuda", dtype=torch.float16):
+                z_ng = ff(xg)
+        else:
+            z_ng = ff(xg)
+    close(z_ng, zr.detach(), tol, "z no-grad")
+    assert set_use_hip_geglu(ff, False) == 1 and "forward" not in ff.__dict__

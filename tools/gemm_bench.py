@@ -132,6 +132,13 @@ def geglu():
         t_f, _, _ = run(lambda: nat.lora_linear_geglu_fwd(x,w,b,4,1.0,packs,True))
         t_fn, _, _ = run(lambda: nat.lora_linear_geglu_fwd(x,w,b,4,1.0,packs,False))
         print(f"proj {M:6d}x{K:5d}x2*{F:5d}: GEMM {t_gemm:6.1f}us | gated (y kept) {t_f:6.1f}us | gated (no y) {t_fn:6.1f}us || host-timed: two launches {timed(two):6.1f}us, fused {timed(lambda: nat.lora_linear_geglu_fwd(x,w,b,4,1.0,packs,True)):6.1f}us", flush=True)
+        # backward: dY = gate-bwd(dz·W2, y) fused against stock mm + the gate kernel (host-timed pairs)
+        w2 = (torch.randn(K,F,device=dev)/F**0.5).to(dtype); w2t = w2.t().contiguous(); dz = torch.randn(M,K,device=dev).to(dtype)
+        y,_ = nat.lora_linear_fwd(x,w,b,a,up,1.0,packs)
+        t_fb, _, _ = run(lambda: nat.geglu_linear_bwd(dz, w2t, y))
+        def two_b():
+            nat.geglu_gate_bwd(y, dz @ w2)
+        print(f"      backward: fused {t_fb:6.1f}us (kernel) || host-timed: stock mm + gate {timed(two_b):6.1f}us, fused {timed(lambda: nat.geglu_linear_bwd(dz, w2t, y)):6.1f}us", flush=True)
 if "--grouped" in sys.argv: grouped()
 elif "--geglu" in sys.argv: geglu()
 elif "--grads" in sys.argv: grads()
