@@ -280,3 +280,38 @@ def test_feed_forward_hook_folds_both_halves_of_the_gate(close, relerr, monkeypa
             z_ng = ff(xg)
     close(z_ng, zr.detach(), tol, "z no-grad")
     assert set_use_hip_geglu(ff, False) == 1 and "forward" not in ff.__dict__
+
+
+@pytest.mark.parametrize("reentrant", [False, True])
+def test_feed_forward_hook_under_activation_checkpointing(relerr, reentrant):
+    """train_lora_dreambooth.py:627-630 (`--gradient_checkpointing`): the hooked block re-runs its forward inside backward;
+    gradients must equal the un-checkpointed ones bit for bit (same kernels, same order)."""
+    from torch.utils.checkpoint import checkpoint
+
+    from diffusion_finetuning_amd.attention import set_use_hip_geglu
+
+    torch.manual_seed(4)
+    ff = _FeedForward(320)
+    ff.requires_grad_(False)
+    dfa.inject_trainable_lora(ff, target_replace_module={"GEGLU"}, r=4)
+    with torch.no_grad():
+        ff.net[0].proj.lora_up.weight.normal_(0, 0.05)
+    ff = ff.to(DEV).half()
+    set_use_hip_geglu(ff)
+    x = torch.randn(2, 300, 320, device=DEV).half()
+    dz = torch.randn(2, 300, 320, device=DEV).half()
+    params = [ff.net[0].proj.lora_down.weight, ff.net[0].proj.lora_up.weight]
+
+    def run(ckpt):
+        for p in params:
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        z = checkpoint(ff, xi, use_reentrant=reentrant) if ckpt else ff(xi)
+        z.backward(dz)
+        return z.detach(), xi.grad, [p.grad.clone() for p in params]
+
+    z0, dx0, g0 = run(False)
+    z1, dx1, g1 = run(True)
+    assert torch.equal(z0, z1) and torch.equal(dx0, dx1)
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
