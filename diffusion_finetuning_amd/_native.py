@@ -13,8 +13,8 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "lib
 _lib = None
 _lock = threading.Lock()
 
-ABI_VERSION = 4
-PROF_KINDS = 10
+ABI_VERSION = 5
+PROF_KINDS = 16
 
 _DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
@@ -50,6 +50,8 @@ SIGNATURES = {
     "lora_pack_factors": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "lora_pack_factors_batched": (_i32, [_vp, _i32, _i32, _vp, _vp, _i32, _vp]),
     "lora_linear_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "lora_linear_fwd_ws": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp, _i64,
+                                  _vp]),
     "lora_linear_geglu_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
     "lora_linear_bwd_input": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
     "lora_linear_bwd_params": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
@@ -215,9 +217,11 @@ def lora_linear_fwd(x2, w, bias, a, b, scale: float, packs=None):
         packs = lora_pack_factors(a, b, x2.dtype)
     y = torch.empty((M, N), dtype=x2.dtype, device=x2.device)
     t = torch.empty((M, r), dtype=torch.float32, device=x2.device)
+    ws = _splitk_workspace(M, K, N, x2)
     _check(
-        lib().lora_linear_fwd(_ptr(x2), _ptr(w), _ptr(bias), _ptr(a), _ptr(b), _ptr(packs[0]), _ptr(packs[1]), _ptr(y),
-                              _ptr(t), M, K, N, r, float(scale), dtype_code(x2.dtype), _stream(x2)),
+        lib().lora_linear_fwd_ws(_ptr(x2), _ptr(w), _ptr(bias), _ptr(a), _ptr(b), _ptr(packs[0]), _ptr(packs[1]), _ptr(y),
+                                 _ptr(t), M, K, N, r, float(scale), dtype_code(x2.dtype), _ptr(ws),
+                                 0 if ws is None else ws.numel() * 4, _stream(x2)),
         "lora_linear_fwd",
     )
     return y, t
@@ -261,15 +265,28 @@ def lora_linear_bwd_input(dy2, wt, a, b, scale: float, need_dx: bool, packs=None
 
 
 _ws_bytes_cache = {}
+_splitk_ws = {}        # device -> persistent workspace (ticket header zeroed ONCE: every launch leaves it zero again)
+_splitk_ws_retired = []  # outgrown workspaces stay alive: a recorded hipGraph may still hold their address
 
 
 def _splitk_workspace(M: int, Kc: int, Nc: int, like):
-    """fp32 scratch for a contraction the library wants to split over K (None when it does not)."""
+    """Scratch for a contraction the library wants to split over K (None when it does not): one buffer per device, grown
+    on demand, shared by every call on the device — the launches are stream-ordered, and the hot path runs on one stream
+    per process (two streams splitting concurrently would need a workspace each: lora_hip.h)."""
     key = (M, Kc, Nc, like.dtype)
     nbytes = _ws_bytes_cache.get(key)
     if nbytes is None:
         nbytes = _ws_bytes_cache[key] = int(lib().lora_gemm_workspace_bytes(M, Kc, Nc, dtype_code(like.dtype)))
-    return torch.empty(nbytes // 4, dtype=torch.float32, device=like.device) if nbytes > 0 else None
+    if nbytes <= 0:
+        return None
+    ws = _splitk_ws.get(like.device)
+    if ws is None or ws.numel() * 4 < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            return None  # never allocate-and-zero inside a recording: this launch simply runs unsplit
+        if ws is not None:
+            _splitk_ws_retired.append(ws)
+        ws = _splitk_ws[like.device] = torch.zeros(max(nbytes, 32 << 20) // 4, dtype=torch.float32, device=like.device)
+    return ws
 
 
 def grad_blocks_for(M: int) -> int:
@@ -525,6 +542,7 @@ def geglu_gate_bwd(y2, dout2):
 
 
 _zero_factors = {}
+_zero_factors_retired = []
 
 
 def geglu_linear_bwd(dz2, w2t, y2):
@@ -536,6 +554,10 @@ def geglu_linear_bwd(dz2, w2t, y2):
     key = (dz2.device, dz2.dtype)
     z = _zero_factors.get(key)
     if z is None or z.numel() < 16 * max(Nz, F):
+        if torch.cuda.is_current_stream_capturing():
+            return None  # (never allocate-and-zero inside a recording: the caller runs the two-launch form)
+        if z is not None:
+            _zero_factors_retired.append(z)  # a recorded hipGraph may still read the old buffer: it stays alive (and zero)
         z = _zero_factors[key] = torch.zeros(16 * max(Nz, F, 10240), dtype=dz2.dtype, device=dz2.device)
     dy = torch.empty_like(y2)
     st = lib().geglu_linear_bwd(_ptr(dz2), _ptr(w2t), _ptr(y2), _ptr(dy), _ptr(z), M, Nz, F, dtype_code(dz2.dtype) if dz2.dtype != torch.float32 else 0,

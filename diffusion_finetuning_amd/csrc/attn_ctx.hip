@@ -451,8 +451,13 @@ int launch_ctx(const CtxArgs& a, const CtxPlan& pl, hipStream_t stream) {
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (attr != hipSuccess) return LORA_E_LAUNCH;
         }
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, static_cast<const T*>(a.Q), static_cast<const T*>(a.K),
-                           static_cast<const T*>(a.V), static_cast<T*>(a.O), a.Tq, a.Tk, a.H, a.d, l2e, pl.rq, pl.chunks, a.ldk);
+        {
+            const double bh = (double)a.B * a.H, e = sizeof(T);
+            lora_prof_set_work(e * bh * a.d * (2.0 * a.Tq + 2.0 * a.Tk), 4.0 * bh * a.Tq * (double)a.Tk * a.d);
+        }
+        LORA_LAUNCH(PK_CTX_FWD, kern, grid, dim3(256), lds, stream, static_cast<const T*>(a.Q), static_cast<const T*>(a.K),
+                    static_cast<const T*>(a.V), static_cast<T*>(a.O), a.Tq, a.Tk, a.H, a.d, l2e, pl.rq, pl.chunks, a.ldk);
+        lora_prof_set_work(0.0, 0.0);
         LORA_LAUNCH_CHECK();
         return LORA_OK;
     } else {
@@ -463,15 +468,21 @@ int launch_ctx(const CtxArgs& a, const CtxPlan& pl, hipStream_t stream) {
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (attr != hipSuccess) return LORA_E_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, dim3(grid.x, (unsigned)pl.slices), dim3(256), lds, stream, static_cast<const T*>(a.Q),
-                       static_cast<const T*>(a.K), static_cast<const T*>(a.V), static_cast<const T*>(a.dO),
-                       static_cast<T*>(a.dQ), a.part, a.Tq,
-                       a.Tk, a.H, a.d, a.scale, l2e, pl.rq, pl.chunks, a.ldk);
+    {   // Q, dO read, dQ written (3·Tq rows); K, V read, dK, dV written (4·Tk rows); S, dP, dQ, dK, dV: 10·B·H·Tq·Tk·d
+        const double bh = (double)a.B * a.H, e = sizeof(T);
+        lora_prof_set_work(e * bh * a.d * (3.0 * a.Tq + 4.0 * a.Tk), 10.0 * bh * a.Tq * (double)a.Tk * a.d);
+    }
+    LORA_LAUNCH(PK_CTX_BWD, kern, dim3(grid.x, (unsigned)pl.slices), dim3(256), lds, stream, static_cast<const T*>(a.Q),
+                static_cast<const T*>(a.K), static_cast<const T*>(a.V), static_cast<const T*>(a.dO),
+                static_cast<T*>(a.dQ), a.part, a.Tq,
+                a.Tk, a.H, a.d, a.scale, l2e, pl.rq, pl.chunks, a.ldk);
+    lora_prof_set_work(0.0, 0.0);
     LORA_LAUNCH_CHECK();
     const int64_t total = (int64_t)a.B * a.Tk * a.H * a.d;
     const unsigned blocks = (unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-    hipLaunchKernelGGL(attn_ctx_reduce_kernel<T>, dim3(blocks), dim3(256), 0, stream, a.part, static_cast<T*>(a.dK),
-                       static_cast<T*>(a.dV), a.B, a.Tk, a.H, a.d, pl.chunks, pl.slices, NKF * 16, DF * 16, a.ld_dk);
+    // (the ordered sum of the chunk partials: its time is recorded as kind "other", it carries no algorithmic bytes)
+    LORA_LAUNCH(PK_OTHER, attn_ctx_reduce_kernel<T>, dim3(blocks), dim3(256), 0, stream, a.part, static_cast<T*>(a.dK),
+                static_cast<T*>(a.dV), a.B, a.Tk, a.H, a.d, pl.chunks, pl.slices, NKF * 16, DF * 16, a.ld_dk);
     LORA_LAUNCH_CHECK();
     return LORA_OK;
     }

@@ -790,9 +790,14 @@ int launch_flash_fwd_v(const FlashArgs& a, hipStream_t stream) {
         if (attr != hipSuccess) return LORA_E_LAUNCH;
     }
     const dim3 grid((unsigned)((a.Tq + 64 * RB - 1) / (64 * RB)), (unsigned)(a.B * a.H));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, static_cast<const T*>(a.Q), static_cast<const T*>(a.K),
-                       static_cast<const T*>(a.V), static_cast<T*>(a.O), a.LSE, a.Tq, a.Tk, a.H, a.d,
-                       a.scale * 1.4426950408889634f, a.ldq);
+    {   // algorithmic work (profiler only): QKᵀ and PV; Q, K, V read and O written once
+        const double bh = (double)a.B * a.H, e = sizeof(T);
+        lora_prof_set_work(e * bh * a.d * (2.0 * a.Tq + 2.0 * a.Tk), 4.0 * bh * a.Tq * (double)a.Tk * a.d);
+    }
+    LORA_LAUNCH(PK_FLASH_FWD, kern, grid, dim3(256), lds, stream, static_cast<const T*>(a.Q), static_cast<const T*>(a.K),
+                static_cast<const T*>(a.V), static_cast<T*>(a.O), a.LSE, a.Tq, a.Tk, a.H, a.d,
+                a.scale * 1.4426950408889634f, a.ldq);
+    lora_prof_set_work(0.0, 0.0);
     LORA_LAUNCH_CHECK();
     return LORA_OK;
 }
@@ -839,9 +844,15 @@ int launch_flash_bwd(const FlashBwdArgs& a, hipStream_t stream) {
             if (attr != hipSuccess) return LORA_E_LAUNCH;
         }
         const dim3 grid((unsigned)((a.Tq + 64 * RBQ - 1) / (64 * RBQ)), (unsigned)(a.B * a.H));
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, static_cast<const T*>(a.Q), static_cast<const T*>(a.K),
-                           static_cast<const T*>(a.V), static_cast<const T*>(a.O), static_cast<const T*>(a.dO), a.LSE,
-                           a.delta, static_cast<T*>(a.dQ), a.Tq, a.Tk, a.H, a.d, a.scale, l2e, a.ldq, a.ld_dq);
+        {   // algorithmic work of the backward = 10·B·H·Tq·Tk·d (S, dP, dQ, dK, dV once each); this launch is charged dQ and
+            // half of the shared S / dP (4·), the dK/dV launch the rest (6·) — both kernels really recompute S and dP
+            const double bh = (double)a.B * a.H, e = sizeof(T);
+            lora_prof_set_work(e * bh * a.d * (4.0 * a.Tq + 2.0 * a.Tk), 4.0 * bh * a.Tq * (double)a.Tk * a.d);
+        }
+        LORA_LAUNCH(PK_FLASH_DQ, kern, grid, dim3(256), lds, stream, static_cast<const T*>(a.Q), static_cast<const T*>(a.K),
+                    static_cast<const T*>(a.V), static_cast<const T*>(a.O), static_cast<const T*>(a.dO), a.LSE,
+                    a.delta, static_cast<T*>(a.dQ), a.Tq, a.Tk, a.H, a.d, a.scale, l2e, a.ldq, a.ld_dq);
+        lora_prof_set_work(0.0, 0.0);
         LORA_LAUNCH_CHECK();
     }
     {
@@ -853,10 +864,15 @@ int launch_flash_bwd(const FlashBwdArgs& a, hipStream_t stream) {
             if (attr != hipSuccess) return LORA_E_LAUNCH;
         }
         const dim3 grid((unsigned)((a.Tk + 64 * NKW - 1) / (64 * NKW)), (unsigned)(a.B * a.H));
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, static_cast<const T*>(a.Q), static_cast<const T*>(a.K),
-                           static_cast<const T*>(a.V), static_cast<const T*>(a.dO), a.LSE, a.delta,
-                           static_cast<T*>(a.dK), static_cast<T*>(a.dV), a.Tq, a.Tk, a.H, a.d, a.scale, l2e, a.ldq,
-                           a.ld_dq);
+        {
+            const double bh = (double)a.B * a.H, e = sizeof(T);
+            lora_prof_set_work(e * bh * a.d * (2.0 * a.Tq + 4.0 * a.Tk), 6.0 * bh * a.Tq * (double)a.Tk * a.d);
+        }
+        LORA_LAUNCH(PK_FLASH_DKDV, kern, grid, dim3(256), lds, stream, static_cast<const T*>(a.Q), static_cast<const T*>(a.K),
+                    static_cast<const T*>(a.V), static_cast<const T*>(a.dO), a.LSE, a.delta,
+                    static_cast<T*>(a.dK), static_cast<T*>(a.dV), a.Tq, a.Tk, a.H, a.d, a.scale, l2e, a.ldq,
+                    a.ld_dq);
+        lora_prof_set_work(0.0, 0.0);
         LORA_LAUNCH_CHECK();
     }
     return LORA_OK;

@@ -93,7 +93,11 @@ static inline bool lora_zero_ticket(void* workspace, hipStream_t s) {
 // the recorded time is the kernel's own duration, not the gap between host-side event records.
 enum ProfKernel {
     PK_GEMM_128x128 = 0, PK_GEMM_256x128, PK_GEMM_64x64, PK_SKINNY_128, PK_SKINNY_64,
-    PK_GRAD_R4, PK_GRAD_R8, PK_GRAD_R16, PK_MSE, PK_OTHER, PK_COUNT
+    PK_GRAD_R4, PK_GRAD_R8, PK_GRAD_R16, PK_MSE, PK_OTHER,
+    PK_GATED_BWD,                                  // frozen ff.net.2 backward-input GEMM with the GEGLU gate's backward (f-4)
+    PK_FLASH_FWD, PK_FLASH_DQ, PK_FLASH_DKDV,      // long-context attention core (f-4)
+    PK_CTX_FWD, PK_CTX_BWD,                        // short-context attention core (f-4)
+    PK_COUNT
 };
 static_assert(PK_COUNT == LORA_PROF_KINDS, "lora_hip.h LORA_PROF_KINDS out of date");
 void lora_prof_set_work(double bytes, double flops);

@@ -61,12 +61,16 @@ struct GemmParams {
     //         into P} — blockIdx covers (row tile, part), every part contracts its own column range of Am.
     const int* tile_part;
     const int64_t* part_table;
-    // Split-K (long contractions on grids too small for the chip): slice s of a tile contracts K-steps
-    // [s·steps_per_slice, …) and STORES its fp32 partial tile at ws_c[s][M][Nc] and its partial P at ws_p[s][M][16];
-    // splitk_reduce_kernel then adds the slices in order, the bias and the rank-r term.  splitk <= 1: off.
+    // Split-K (contractions on grids too small for the chip): slice s of a tile contracts K-steps [s·steps_per_slice, …),
+    // STORES its fp32 accumulators at ws_c[tile][s] (BM·BN floats in the lanes' own register order) and its partial P at
+    // ws_p[tile][s][BM][16], and takes a ticket of the tile.  The workgroup that draws the LAST ticket adds the slices
+    // 0..S-1 in index order — whoever arrives last, the sum has one order: deterministic — and runs the normal epilogue
+    // (rank-r term, bias, store) on the totals; it leaves the ticket at zero for the next launch.  splitk <= 1: off.
     int splitk, steps_per_slice;
     float* ws_c;
     float* ws_p;
+    unsigned* tickets;  // one per output tile, zero on entry, zero again on exit
+    int split_bm;       // (host only) row-tile height of a split launch
     // GEGLU gate in the epilogue (GATE kernels; diffusers GEGLU.forward behind the `proj` LoraInjectedLinear): Nc = 2·gateF,
     // a column tile owns BN/2 columns of h = C[:, :gateF] AND the matching BN/2 columns of g = C[:, gateF:], and the
     // epilogue writes C2[M, gateF] = h·gelu(g) next to C (C may be null: nothing is saved for a backward pass).
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
     // Pull every kernel argument into SGPRs now: one scalar-load round trip instead of two dependent ones.
     asm volatile("" ::"s"(p.Am), "s"(p.Bm), "s"(p.bias), "s"(p.Fp), "s"(p.Qp), "s"(p.C), "s"(p.P), "s"(p.M), "s"(p.Kc),
                  "s"(p.Nc), "s"(p.scale), "s"(p.tiles_m), "s"(p.tiles_n), "s"(p.col_major), "s"(p.lda), "s"(p.tile_part),
-                 "s"(p.part_table), "s"(p.splitk), "s"(p.steps_per_slice), "s"(p.ws_c), "s"(p.ws_p));
+                 "s"(p.part_table), "s"(p.splitk), "s"(p.steps_per_slice), "s"(p.ws_c), "s"(p.ws_p), "s"(p.tickets));
     int tile, slice = 0;
     {
         const int S = p.splitk > 1 ? p.splitk : 1;
@@ -432,7 +436,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
             char* const refill = smem + (buf >= 1 ? buf - 1 : kStages - 1) * STAGE;  // the buffer read last step
             if (kt + DIST < nk) {
                 if (!(p.dbg & 1)) issue(kt + DIST, buf >= 1 ? buf - 1 : kStages - 1);
-            } else if (MAIN && kt == nk - 1 && p.splitk <= 1) {
+            } else if (MAIN && kt == nk - 1) {  // (every K-slice of a split tile: any of them may turn out to be the last arriver)
                 sQ = refill + QOFF;  // nothing left to prefetch: the epilogue's Q tile takes the free buffer
                 issue_q(sQ);
             }
@@ -512,37 +516,104 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
     }
     __syncthreads();
 
-    if (p.splitk > 1) {
-        // this slice's partial sums: P (all 16 rank slots, first column tile only) and the fp32 accumulators, straight
-        // from the registers (a lane owns 4 consecutive columns: 16-byte stores)
-        if (tn == 0) {
-            const int half = tid & 1;
-            for (int row = tid >> 1; row < BM && m0 + row < p.M; row += NT / 2) {
-                float v[8];
+    if constexpr (PIPE && GATE == 0) {
+        if (p.splitk > 1) {
+            // In-launch split-K combine (cdna_hip_programming.md, "Projection GEMM" item 2, the sc1 form): every byte that
+            // crosses workgroups is stored WRITE-THROUGH (sc1) and loaded sc1 — the XCDs' L2s are not coherent with each
+            // other and a CU's L1 is never refreshed, so plain accesses would need an agent-scope release in every slice
+            // (an L2 write-back: measured 4–10× the whole kernel) and an acquire in the reducer.  Order: sc1 stores → every
+            // wave drains its stores (vmcnt(0)) → workgroup barrier → ONE lane draws the ticket (agent-scope atomic).
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const int S = p.splitk;
+            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
+                p.ws_c + (int64_t)tile * S * (BM * BN), 0, MAIN ? S * BM * BN * 4 : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+                p.ws_p + (int64_t)tile * S * (BM * kRP), 0, S * BM * kRP * 4, 0x00020000);
+            // (a) this slice's partial sums: P (all 16 rank slots; every column tile keeps its own copy, its last arriver
+            // needs it) and the fp32 accumulators in the lanes' own register order — perfectly coalesced 16-byte stores,
+            // no edge handling (rows / columns past the edge are never stored to C)
+            {
+                const int half = tid & 1;
+                for (int row = tid >> 1; row < BM; row += NT / 2) {
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    v[e] = 0.f;
-#pragma unroll
-                    for (int w = 0; w < WN; ++w) v[e] += sP[(w * BM + row) * kSPS + half * 8 + e];
+                    for (int w = 0; w < WN; ++w) {
+                        const f32x4* src = reinterpret_cast<const f32x4*>(&sP[(w * BM + row) * kSPS + half * 8]);
+                        a += src[0];
+                        b += src[1];
+                    }
+                    const int off = ((slice * BM + row) * kRP + half * 8) * 4;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a), rp, off, 0, 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, b), rp, off + 16, 0, 16);
                 }
-                float* dst = p.ws_p + ((int64_t)slice * p.M + m0 + row) * kRP + half * 8;
-                *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-                *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
             }
-        }
-        if constexpr (MAIN) {
-            float* wc = p.ws_c + (int64_t)slice * p.M * p.Nc;
+            if constexpr (MAIN) {
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const int64_t m = m0 + wm * WTM + mi * 16 + l15;
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    const int col = n0 + wn * WTN + ni * 16 + lq * 4;
-                    if (m < p.M && col < p.Nc) *reinterpret_cast<f32x4*>(wc + m * p.Nc + col) = acc[mi][ni];
+                    for (int ni = 0; ni < NI; ++ni)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[mi][ni]), rc,
+                                                               (slice * (BM * BN) + ((mi * NI + ni) * NT + tid) * 4) * 4, 0, 16);
+            }
+            // (b) ticket.  The flag lives in the buffer of the last K-step, free since the barrier behind the P exchange.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains before the barrier
+            __syncthreads();
+            volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(last_buf);
+            if (tid == 0) {
+                const unsigned old = __hip_atomic_fetch_add(p.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool last = old == (unsigned)(S - 1);
+                if (last) __hip_atomic_store(p.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *flag = last ? 1u : 0u;
+            }
+            __syncthreads();
+            if (*flag == 0u) return;
+            // (c) the last arriver: totals over the slices in index order (its own contribution included, from memory, so
+            // that the order of the additions never depends on who came last).  EVERY load of a slab is an sc1 load.
+            if constexpr (MAIN) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+                for (int s = 0; s < S; ++s) {
+                    u32x4 v[MI][NI];
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+                            v[mi][ni] = __builtin_amdgcn_raw_buffer_load_b128(
+                                rc, (s * (BM * BN) + ((mi * NI + ni) * NT + tid) * 4) * 4, 0, 16);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] += __builtin_bit_cast(f32x4, v[mi][ni]);
                 }
             }
+            {
+                // total P of the tile's rows goes into wave slot 0 of the P image, zeros into the other slots: everything
+                // below sums the slots exactly as it does for an unsplit tile
+                const int half = tid & 1;
+                for (int row = tid >> 1; row < BM; row += NT / 2) {
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+                    for (int s = 0; s < S; ++s) {
+                        const int off = ((s * BM + row) * kRP + half * 8) * 4;
+                        a += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, off, 0, 16));
+                        b += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, off + 16, 0, 16));
+                    }
+                    f32x4* dst = reinterpret_cast<f32x4*>(&sP[row * kSPS + half * 8]);
+                    dst[0] = a;
+                    dst[1] = b;
+#pragma unroll
+                    for (int w = 1; w < WN; ++w) {
+                        f32x4* z = reinterpret_cast<f32x4*>(&sP[(w * BM + row) * kSPS + half * 8]);
+                        z[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        z[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+            }
+            __syncthreads();
         }
-        return;
     }
     constexpr bool PACKED_P = MAIN && !F32 && PIPE;  // the rank-r term's operand is built ONCE per row, cooperatively
     constexpr int kPkStride = 80;                     // bytes per row of the packed image [hi j0..15 | lo j0..15] (+16 pad)
@@ -898,133 +969,43 @@ __global__ __launch_bounds__(256) void pack_factors_batched_kernel(const int64_t
                 blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
-// Second half of a split-K launch: C[m,n] = T( Σ_s ws_c[s][m][n] + bias[n] + scale·Σ_j P[m][j]·Q[n][j] ),
-// P[m][j] = Σ_s ws_p[s][m][j] (also written out, unscaled).  Slices are added in index order: deterministic.
-// A workgroup owns 16 rows × 128 columns (blockIdx.y = column block); thread = 8 consecutive columns of one row.
-// S is a template parameter so that all slice loads of a trip are in flight together (a run-time loop waits for each).
-template <typename T, int S>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws_c, const float* ws_p, const void* bias_,
-                                                            const void* Qp_, void* C_, float* P_out, int64_t M, int Nc,
-                                                            int r, float scale) {
-    __shared__ float sPs[16][kRP];
-    const int64_t m0 = (int64_t)blockIdx.x * 16;
-    {
-        const int row = threadIdx.x >> 4, j = threadIdx.x & 15;  // 256 threads = 16 rows × 16 rank slots
-        const int64_t ml = m0 + row < M ? m0 + row : M - 1;
-        float part[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) part[s] = ws_p[((int64_t)s * M + ml) * kRP + j];
-        float v = 0.f;
-#pragma unroll
-        for (int s = 0; s < S; ++s) v += part[s];
-        sPs[row][j] = v;
-        if (blockIdx.y == 0 && P_out != nullptr && m0 + row < M && j < r) P_out[(m0 + row) * r + j] = v;
-    }
-    __syncthreads();
-    const T* bias = static_cast<const T*>(bias_);
-    const T* Qp = static_cast<const T*>(Qp_);
-    T* C = static_cast<T*>(C_);
-    const int cb = blockIdx.y * 128;                                  // first column of this block
-    const int chunks = (Nc - cb < 128 ? Nc - cb : 128) >> 3;          // Nc % 8 == 0 on this path
-    const int64_t slice = M * (int64_t)Nc;
-    for (int idx = threadIdx.x; idx < 16 * chunks; idx += 256) {
-        const int row = idx / chunks, c8 = cb + ((idx - row * chunks) << 3);
-        const int64_t m = m0 + row < M ? m0 + row : M - 1;  // clamped: rows past the end are computed, not stored
-        const float* src = ws_c + m * Nc + c8;
-        f32x4 a[S], b[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            a[s] = *reinterpret_cast<const f32x4*>(src + s * slice);
-            b[s] = *reinterpret_cast<const f32x4*>(src + s * slice + 4);
-        }
-        float q[8][kRP];
-        if constexpr (sizeof(T) == 2) {  // the 8 packed rows of Q (16 values each) as 16-byte loads
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const Chunk<T> lo = *reinterpret_cast<const Chunk<T>*>(Qp + (int64_t)(c8 + e) * kRP);
-                const Chunk<T> hi = *reinterpret_cast<const Chunk<T>*>(Qp + (int64_t)(c8 + e) * kRP + 8);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    q[e][j] = to_f32<T>(lo.v[j]);
-                    q[e][8 + j] = to_f32<T>(hi.v[j]);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-#pragma unroll
-                for (int j = 0; j < kRP; ++j) q[e][j] = to_f32<T>(Qp[(int64_t)(c8 + e) * kRP + j]);
-        }
-        float acc[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-#pragma unroll
-        for (int s = 0; s < S; ++s)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[e] += a[s][e];
-                acc[4 + e] += b[s][e];
-            }
-        float bv[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bv[e] = 0.f;
-        if (bias != nullptr) {
-            if constexpr (sizeof(T) == 2) {
-                const Chunk<T> bc = *reinterpret_cast<const Chunk<T>*>(bias + c8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bv[e] = to_f32<T>(bc.v[e]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bv[e] = to_f32<T>(bias[c8 + e]);
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float l = 0.f;
-#pragma unroll
-            for (int j = 0; j < kRP; ++j) l = fmaf(sPs[row][j], q[e][j], l);  // unused rank slots of Q are zero
-            acc[e] += scale * l + bv[e];
-        }
-        if (m0 + row >= M) continue;
-        T* dst = C + m * Nc + c8;
-        if constexpr (sizeof(T) == 2) {
-            Chunk<T> out;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) out.v[e] = from_f32<T>(acc[e]);
-            *reinterpret_cast<Chunk<T>*>(dst) = out;
-        } else {
-            *reinterpret_cast<f32x4*>(dst) = f32x4{acc[0], acc[1], acc[2], acc[3]};
-            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
-        }
-    }
-}
-
-template <typename T>
-void launch_splitk_reduce(const GemmParams& p, int S, hipStream_t stream) {
-    const dim3 grid((unsigned)((p.M + 15) / 16), (unsigned)((p.Nc + 127) / 128));
-#define SK_CASE(S_)                                                                                            \
-    case S_:                                                                                                   \
-        LORA_LAUNCH(PK_OTHER, (splitk_reduce_kernel<T, S_>), grid, dim3(256), 0, stream, p.ws_c, p.ws_p, p.bias, p.Qp, p.C, \
-                    p.P, p.M, p.Nc, p.r, p.scale);                                                             \
-        break;
-    switch (S) { SK_CASE(2) SK_CASE(3) SK_CASE(4) SK_CASE(5) SK_CASE(6) SK_CASE(7) SK_CASE(8) default: break; }
-#undef SK_CASE
-}
-
-// Split-K plan: only for long contractions whose 128×128 grid cannot fill the chip.  Returns the slice count (1 = off).
-int plan_splitk(int64_t M, int Kc, int Nc, int esize) {
+// Split-K plan.  Splitting buys chip occupancy with a combine that costs the tile ≈ 5–6 µs (write-through slab stores, the
+// ticket's round trip, the last arriver's serial slab reads at the cross-XCD rate), so it pays only for LONG contractions on
+// under-filled grids: measured (tools/splitk_sweep.sh, weights cold) the 20-K-step 1280-wide projections LOSE 2–3 µs at
+// every slice count (1024×1280×1280: 15.7 → 18.5 µs), the 60-K-step grouped q/k/v backward gains 5–8 µs (35 → 30, 26 → 19),
+// the 80/160-K-step GEGLU `proj` backward 18–30 µs (66 → 48, 84 → 54, 62 → 31).  Returns the slice count (1 = off) and the
+// row-tile height of the split launch: ≈ 480 workgroups, 64-row tiles on the small grids (two per CU overlap each other's
+// phases), at least 10 K-steps left per slice.
+struct SplitPlan {
+    int S, bm;
+};
+constexpr int kTicketBytes = LORA_GEMM_WS_TICKET_BYTES;  // ticket header of the workspace: one u32 per output tile
+SplitPlan plan_splitk(int64_t M, int Kc, int Nc, int esize) {
     static const int env = [] { const char* e = getenv("LORA_SPLITK"); return e ? atoi(e) : -1; }();
-    if (env == 0) return 1;
+    static const int env_bm = [] { const char* e = getenv("LORA_SPLIT_BM"); return e ? atoi(e) : 0; }();
+    static const int env_min = [] { const char* e = getenv("LORA_SPLIT_MINSTEPS"); return e ? atoi(e) : 0; }();
+    SplitPlan off{1, 128};
+    if (env == 0) return off;
     const int nk = (Kc * esize + kRowBytes - 1) / kRowBytes;
-    const int64_t tiles = ((M + 127) / 128) * ((Nc + 127) / 128);
-    // measured (tools/gemm_bench.py): wins from 64 K-steps up (GEGLU proj backward, 80 / 160 K-steps: 62→52, 72→54,
-    // 69→35 µs); at 30 / 60 K-steps (grouped q/k/v backward) the second launch costs what the split gains
-    if (nk < 64 || tiles > 192 || (Nc & 7) != 0 || (Kc * esize) % kRowBytes != 0) return 1;
-    int S = (int)((384 + tiles - 1) / tiles);  // aim at ~1.5 workgroups per CU
+    const int64_t tiles128 = ((M + 127) / 128) * ((Nc + 127) / 128);
+    const int64_t tiles64 = ((M + 63) / 64) * ((Nc + 127) / 128);
+    if ((Nc & 7) != 0 || (Kc * esize) % kRowBytes != 0 || tiles128 >= 192) return off;
+    if (env <= 0 && nk < 48) return off;
+    int bm = tiles128 <= 96 ? 64 : 128;
+    if (env_bm == 64 || env_bm == 128) bm = env_bm;
+    const int64_t tiles = bm == 64 ? tiles64 : tiles128;
+    if (tiles > kTicketBytes / 4) return off;
+    int S = (int)((480 + tiles / 2) / tiles);
     if (S > 8) S = 8;
-    while (S > 1 && nk / S < 8) --S;           // keep >= 8 K-steps per slice: below that the fixed phases dominate
+    const int min_steps = env_min > 0 ? env_min : 10;
+    while (S > 1 && nk / S < min_steps) --S;
     if (env > 1) S = env > 8 ? 8 : env;
-    return S;
+    while (S > 1 && (S - 1) * ((nk + S - 1) / S) >= nk) --S;  // every slice owns at least one K-step
+    return SplitPlan{S, bm};
+}
+int64_t splitk_ws_bytes(int64_t M, int Nc, const SplitPlan& sp) {
+    const int64_t tm = (M + sp.bm - 1) / sp.bm, tn = (Nc + 127) / 128;
+    return kTicketBytes + tm * tn * sp.S * ((int64_t)sp.bm * 128 + (int64_t)sp.bm * kRP) * 4;
 }
 
 // Generalised packing for grouped layers: one table row per FACTOR,
@@ -1065,13 +1046,12 @@ int launch_tile(GemmParams p, hipStream_t stream) {
     constexpr int prof_id = MAIN ? (NW == 8 ? PK_GEMM_256x128 : (BM == 128 ? PK_GEMM_128x128 : PK_GEMM_64x64))
                                  : (BM == 128 ? PK_SKINNY_128 : PK_SKINNY_64);
     const int S = p.splitk > 1 ? p.splitk : 1;
+    if (S > 1) {  // workspace = [tickets | fp32 tiles | P tiles] (splitk_ws_bytes)
+        p.ws_c = reinterpret_cast<float*>(reinterpret_cast<char*>(p.tickets) + kTicketBytes);
+        p.ws_p = p.ws_c + (int64_t)p.tiles_m * p.tiles_n * S * (BM * BN);
+    }
     LORA_LAUNCH(prof_id, kern, dim3(p.tiles_m * p.tiles_n * S), dim3(NW * 64), lds, stream, p);
     LORA_LAUNCH_CHECK();
-    if (S > 1) {
-        lora_prof_set_work(0.0, 0.0);  // the reduction's time is recorded (kind "other"); its bytes are not algorithmic
-        launch_splitk_reduce<T>(p, S, stream);
-        LORA_LAUNCH_CHECK();
-    }
     return LORA_OK;
 }
 
@@ -1104,7 +1084,7 @@ int launch_gate_bwd(GemmParams p, hipStream_t stream) {
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr != hipSuccess) return LORA_E_LAUNCH;
-    LORA_LAUNCH(PK_GEMM_128x128, kern, dim3(p.tiles_m * p.tiles_n), dim3(256), lds, stream, p);
+    LORA_LAUNCH(PK_GATED_BWD, kern, dim3(p.tiles_m * p.tiles_n), dim3(256), lds, stream, p);
     LORA_LAUNCH_CHECK();
     return LORA_OK;
 }
@@ -1136,7 +1116,10 @@ int launch_pipe(const GemmParams& p_in, hipStream_t stream) {
     p.dbg = dbg_env;
     if (!MAIN) return launch_tile<T, 64, 64, false, 3>(p, stream);
     static const int stg_env = [] { const char* e = getenv("LORA_FORCE_STAGES"); return e ? atoi(e) : 0; }();
-    if (p.splitk > 1) return launch_tile<T, 128, 128, true, 2>(p, stream);
+    if (p.splitk > 1) {  // (tile height from plan_splitk: the workspace was sized for it)
+        if (p.split_bm == 64) return launch_tile<T, 64, 128, true, 3, 4>(p, stream);
+        return launch_tile<T, 128, 128, true, 2, 4>(p, stream);
+    }
     if (p.tile_part != nullptr) {  // grouped: 64-wide column tiles never straddle two parts
         const int64_t t64 = ((p.M + 63) / 64) * ((p.Nc + 63) / 64);
         return t64 < 512 ? launch_tile<T, 64, 64, true, 3>(p, stream) : launch_tile<T, 64, 64, true, 2>(p, stream);
@@ -1231,15 +1214,14 @@ int launch_typed(const CallArgs& c, bool main_part, hipStream_t stream) {
         p.Am = c.Am; p.Bm = c.Bm; p.bias = c.bias; p.Fp = c.Fp; p.Qp = c.Qp;
         p.C = c.C; p.P = c.P; p.M = c.M; p.Kc = c.Kc; p.Nc = c.Nc; p.r = c.r; p.scale = c.scale;
         p.lda = lda; p.tile_part = c.tile_part; p.part_table = c.part_table; p.tiles_n = c.n_parts;
-        if (main_part && !grouped && c.workspace != nullptr && aligned16(c.workspace)) {
-            const int S = plan_splitk(c.M, c.Kc, c.Nc, (int)sizeof(T));
-            const int64_t need = (int64_t)S * c.M * ((int64_t)c.Nc + kRP) * 4;
-            if (S > 1 && c.ws_bytes >= need) {
+        if (main_part && !grouped && c.workspace != nullptr && aligned16(c.workspace) && (c.Kc % BK) == 0) {
+            const SplitPlan sp = plan_splitk(c.M, c.Kc, c.Nc, (int)sizeof(T));
+            if (sp.S > 1 && c.ws_bytes >= splitk_ws_bytes(c.M, c.Nc, sp)) {
                 const int nk = c.Kc / BK;
-                p.splitk = S;
-                p.steps_per_slice = (nk + S - 1) / S;
-                p.ws_c = static_cast<float*>(c.workspace);
-                p.ws_p = p.ws_c + (int64_t)S * c.M * c.Nc;
+                p.splitk = sp.S;
+                p.split_bm = sp.bm;
+                p.steps_per_slice = (nk + sp.S - 1) / sp.S;
+                p.tickets = static_cast<unsigned*>(c.workspace);
             }
         }
         if ((c.Kc % BK) == 0) return main_part ? launch_pipe<T, true>(p, stream) : launch_pipe<T, false>(p, stream);
@@ -1374,6 +1356,12 @@ extern "C" int lora_pack_items(const int64_t* table, int n_items, int max_len, c
 extern "C" int lora_linear_fwd(const void* X, const void* W, const void* bias, const float* A, const float* B,
                                const void* Apack, const void* Bpack, void* Y, float* T_out, int64_t M, int K, int N,
                                int r, float scale, int dtype, void* stream) {
+    return lora_linear_fwd_ws(X, W, bias, A, B, Apack, Bpack, Y, T_out, M, K, N, r, scale, dtype, nullptr, 0, stream);
+}
+
+extern "C" int lora_linear_fwd_ws(const void* X, const void* W, const void* bias, const float* A, const float* B,
+                                  const void* Apack, const void* Bpack, void* Y, float* T_out, int64_t M, int K, int N,
+                                  int r, float scale, int dtype, void* workspace, int64_t ws_bytes, void* stream) {
     const int st = check_common(M, K, N, r, dtype);
     if (st != LORA_OK) return st;
     if (M == 0) return LORA_OK;  // empty batch: nothing to do (pointers may be null)
@@ -1387,6 +1375,7 @@ extern "C" int lora_linear_fwd(const void* X, const void* W, const void* bias, c
     c.Q = B; c.q_sn = r; c.q_sj = 1;               // Q[n,j] = B[n,j]
     c.C = Y; c.P = T_out;
     c.M = M; c.Kc = K; c.Nc = N; c.r = r; c.scale = scale;
+    c.workspace = workspace; c.ws_bytes = ws_bytes;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const double e = esize(dtype);
     ProfWork work(e * ((double)M * K + (double)N * K + (double)M * N) + e * r * (K + N) + (bias ? e * N : 0.0),
@@ -1445,8 +1434,8 @@ extern "C" int geglu_linear_bwd(const void* dZ, const void* W2t, const void* Y, 
 
 extern "C" int64_t lora_gemm_workspace_bytes(int64_t M, int Kc, int Nc, int dtype) {
     if (M < 1 || Kc < 1 || Nc < 1) return 0;
-    const int S = plan_splitk(M, Kc, Nc, dtype == LORA_F32 ? 4 : 2);
-    return S > 1 ? (int64_t)S * M * ((int64_t)Nc + kRP) * 4 : 0;
+    const SplitPlan sp = plan_splitk(M, Kc, Nc, dtype == LORA_F32 ? 4 : 2);
+    return sp.S > 1 ? splitk_ws_bytes(M, Nc, sp) : 0;
 }
 
 extern "C" int lora_linear_bwd_input(const void* dY, const void* Wt, const float* A, const float* B,

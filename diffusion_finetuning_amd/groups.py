@@ -244,6 +244,17 @@ class CtxKVGroup:
     def new_pass(self):
         self._pass = None
 
+    def check_pass_complete(self):
+        """Called when the slab collects a step's factor gradients: a backward pass that reached SOME of the pass's
+        cross-attentions but not all (one whose output took no part in the loss) never handed the shared dK/dV buffer to
+        autograd — every to_k/to_v factor gradient of the group would silently be zero."""
+        st = self._pass
+        if st is not None and 0 < st.returned < st.consumers:
+            raise RuntimeError(
+                f"CtxKVGroup: backward reached {st.returned} of the {st.consumers} cross-attentions that shared this pass's "
+                "K/V projection; the grouped projection's gradient was never produced.  Build the trainer with "
+                "group_projections=False for models whose loss does not depend on every cross-attention.")
+
     def usable(self, ctx_t: torch.Tensor, cdtype: torch.dtype) -> bool:
         # Not under gradient checkpointing (train_lora_dreambooth.py:627-630): it re-runs one block's forward at a time
         # inside backward (reentrant form) or replays what a block saved (non-reentrant form), and the group's shared
@@ -347,7 +358,11 @@ class _CtxAttnKVFn(torch.autograd.Function):
         dq = nat.attn_ctx_bwd_kv(q, kv, st.dkv, ctx.offs[0], ctx.offs[1], dout if dout.is_contiguous() else dout.contiguous(),
                                  ctx.heads, ctx.scale)
         st.returned += 1
-        dkv = st.dkv if st.returned == st.consumers else None
+        dkv = None
+        if st.returned == st.consumers:
+            # the last consumer hands the buffer over and closes the pass: a second backward over the same graph
+            # (retain_graph) starts counting — and filling a fresh buffer — again
+            dkv, st.dkv, st.returned = st.dkv, None, 0
         return dq, dkv, None, None, None, None, None
 
 

@@ -241,6 +241,8 @@ class LoraSlab:
 
     def flush(self):
         """Launch every deferred problem, then fold the partial sums of the layers that ran into `grads` (+=)."""
+        for grp in self.ctx_groups:
+            grp.check_pass_complete()
         if not self._pending:
             return
         for dt, problems in self._pending.items():
@@ -334,13 +336,17 @@ class SlabExchange:
         # on a single GPU)
         self.active = self.world > 1 or (always_reduce and dist.is_available() and dist.is_initialized())
         self.early_range: Optional[Tuple[int, int]] = None
+        # single: the whole slab always goes in ONE all-reduce after backward, whatever early_range says.  Set by the
+        # trainer whenever a recorded (hipGraph) step was ASKED for: a replayed step can only exchange that way, and a rank
+        # whose recording failed — or whose step is not recordable — must keep issuing the same collectives as its peers.
+        self.single = False
         self._armed = False
         self._early_sent = False
         self._pending = []
 
     def arm(self):
         """Call before each backward pass; launch_early() then fires at most once."""
-        self._armed = self.active and self.early_range is not None
+        self._armed = self.active and self.early_range is not None and not self.single
         self._early_sent = False
 
     def _send(self, a: int, b: int):
@@ -374,6 +380,44 @@ class SlabExchange:
         self._early_sent = False
 
 
+class LossScaler:
+    """torch.cuda.amp.GradScaler's scale schedule at a FIXED LAG, so that every data-parallel rank changes its scale at
+    the same step: an overflowed (hence skipped) step halves the loss scale, `growth_interval` clean steps double it again
+    (never above the initial value).  The overflow flag of step k is shipped to the host without a wait when step k ends
+    (`watch`) and is applied at the start of step k + LAG (`begin_step`), after a wait on an event that completed long
+    ago — never "whenever the copy happens to have landed", which differs from rank to rank: ranks that disagree on the
+    scale for even one step mix gradients scaled by S and S/2 in the SUM all-reduce and drift apart for good.  The flag
+    itself is computed on the all-reduced slab, so it is identical everywhere.  Device-agnostic (`watch` takes a callable
+    that returns the flag once awaited): the GPU trainer hands it a pinned-buffer reader, the CPU tests plain floats."""
+
+    LAG = 2
+
+    def __init__(self, initial: float, growth_interval: int = 2000):
+        self.scale = float(initial)
+        self.initial = float(initial)
+        self.growth_interval = int(growth_interval)
+        self.clean_steps = 0
+        self._inflight = []  # FIFO of callables, one per finished step
+
+    def watch(self, read_flag):
+        self._inflight.append(read_flag)
+
+    def begin_step(self) -> bool:
+        """Applies the decision of the step that ended LAG steps ago; True when the scale changed."""
+        if len(self._inflight) < self.LAG:
+            return False
+        overflow = float(self._inflight.pop(0)()) != 0.0
+        before = self.scale
+        if overflow:
+            self.scale = max(1.0, self.scale * 0.5)
+            self.clean_steps = 0
+        else:
+            self.clean_steps += 1
+            if self.clean_steps >= self.growth_interval and self.scale < self.initial:
+                self.scale, self.clean_steps = min(self.initial, self.scale * 2.0), 0
+        return self.scale != before
+
+
 class LoraTrainer:
     """One object per process (= per GPU).  `step()` runs one full training step and returns the loss tensor
     (no host sync unless the caller reads it)."""
@@ -382,10 +426,11 @@ class LoraTrainer:
                  weight_decay=1e-2, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0, loss_scale: Optional[float] = None,
                  v_prediction=False, process_group=None, always_reduce=False, capture_graph=False,
                  group_projections=True):
-        """capture_graph: record add_noise → UNet forward → loss → backward of a step once into a hipGraph and
-        replay it on later steps with the same shapes (inputs are copied into static buffers).  The partial-sum fold,
-        the gradient exchange and the optimizer stay outside the graph, so no collective is ever captured.  Only the
-        plain UNet step is eligible (no text-encoder LoRA, no mask); anything else runs eagerly.
+        """capture_graph: record add_noise → [text encoder] → UNet forward → loss → backward → factor gradients of a step
+        once into a hipGraph and replay it on later steps with the same shapes (inputs are copied into static buffers).
+        The gradient exchange and the optimizer stay outside the graph, so no collective is ever captured.  A step with a
+        LoRA text encoder is recordable when the caller hands over `input_ids` (the encoder's forward then belongs to the
+        step, train_lora_dreambooth.py:840); a mask is a static input like the latents.  Anything else runs host-launched.
         group_projections: run attn1 to_q/to_k/to_v as one launch per block and the attn2 to_k/to_v of all blocks as one
         launch per pass (groups.py; effective for attention modules switched to the HIP cores with the reference's
         `set_use_memory_efficient_attention_xformers`)."""
@@ -393,6 +438,7 @@ class LoraTrainer:
         self.capture_graph = bool(capture_graph)
         self._graph = None
         models = [unet] + ([text_encoder] if text_encoder is not None and lora_layers(text_encoder) else [])
+        self.trains_text_encoder = len(models) > 1
         self.slab = LoraSlab(models)
         if group_projections:
             self.slab.enable_groups()
@@ -402,18 +448,34 @@ class LoraTrainer:
         self.opt = FusedClipAdamW(self.slab, groups, betas, eps, max_grad_norm)
         self.device = self.slab.params.device
         self.dtype = next(p for p in unet.parameters() if p.dim() == 4).dtype  # conv weight dtype = compute dtype
-        self.loss_scale = float(loss_scale) if loss_scale is not None else (1024.0 if self.dtype == torch.float16 else 1.0)
-        self._initial_scale, self._clean_steps, self._flag_event, self._warned_overflow = self.loss_scale, 0, None, False
-        self._flag_host = torch.zeros(1, dtype=torch.float32).pin_memory() if self.loss_scale != 1.0 else None
+        initial = float(loss_scale) if loss_scale is not None else (1024.0 if self.dtype == torch.float16 else 1.0)
+        self.scaler = LossScaler(initial, self.GROWTH_INTERVAL)
+        self._warned_overflow = False
+        # one pinned word + one event per step in flight (LAG + 1: the slot of step k is reused at step k + LAG + 1)
+        self._flag_slots = ([(torch.zeros(1, dtype=torch.float32).pin_memory(), torch.cuda.Event())
+                             for _ in range(LossScaler.LAG + 1)] if initial != 1.0 else None)
+        self._flag_turn = 0
         self.slab.enable_packed(self.dtype)
         self.v_prediction = v_prediction
         self.sqrt_acp, self.sqrt_1macp = ddpm_tables(device=self.device)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.exchange = SlabExchange(self.slab.grads, self.slab.numel, process_group, always_reduce=always_reduce)
+        # A recorded step exchanges the slab in one all-reduce.  Once recording was ASKED for, every step of this trainer
+        # does — also the host-launched ones (recording failed on this rank only, a step that is not recordable): the
+        # collective sequence then depends on what was requested, which is the same on every rank, never on what succeeded.
+        self.exchange.single = self.capture_graph
         if self.exchange.active:
             self._broadcast_initial_state()
             self._install_bucket_hook()
+
+    @property
+    def loss_scale(self) -> float:
+        return self.scaler.scale
+
+    @loss_scale.setter
+    def loss_scale(self, value: float):
+        self.scaler.scale = float(value)
 
     # -- data parallel -------------------------------------------------------------------------
     def _broadcast_initial_state(self):
@@ -426,7 +488,10 @@ class LoraTrainer:
         up blocks first, then mid, then the down blocks — so [up|mid] is a contiguous early bucket whose
         all-reduce overlaps the rest of the backward pass (its factor gradients are launched and folded first).
         Not with a CtxKVGroup: the to_k/to_v gradients of EVERY block then come out of one launch at the end of
-        backward, so no slab range is final before that — the whole slab (5 MB at rank 4) goes in one all-reduce."""
+        backward, so no slab range is final before that — the whole slab (5 MB at rank 4) goes in one all-reduce.
+        (Restoring the overlap there means cutting the K/V group by block range — one group for [up|mid], one for
+        down — at the price of a second 13-µs projection launch per pass; the exchange it would hide is ≈ 60–100 µs of a
+        30-ms step.  DESIGN.md §6.)"""
         mid = getattr(self.unet, "mid_block", None)
         ups = getattr(self.unet, "up_blocks", None)
         if mid is None or ups is None or self.slab.ctx_groups:
@@ -448,33 +513,31 @@ class LoraTrainer:
     GROWTH_INTERVAL = 2000  # torch.cuda.amp.GradScaler's default
 
     def _watch_overflow(self):
-        """Ship the step's overflow flag to pinned host memory without waiting for it."""
-        if self._flag_host is not None and self._flag_event is None:
-            self._flag_host.copy_(self.opt.norm[1:2], non_blocking=True)
-            self._flag_event = torch.cuda.Event()
-            self._flag_event.record()
+        """Ship the step's overflow flag to pinned host memory without waiting for it; LossScaler.begin_step reads it
+        LAG steps later, behind a wait on the event recorded here (complete by then: the wait costs nothing)."""
+        if self._flag_slots is None:
+            return
+        host, ev = self._flag_slots[self._flag_turn]
+        self._flag_turn = (self._flag_turn + 1) % len(self._flag_slots)
+        host.copy_(self.opt.norm[1:2], non_blocking=True)
+        ev.record()
+
+        def read(host=host, ev=ev):
+            ev.synchronize()
+            return float(host[0])
+
+        self.scaler.watch(read)
 
     def _poll_overflow(self):
-        """GradScaler's scale update, one or two steps late and without a host sync: an overflowed (hence skipped) step
-        halves the loss scale, GROWTH_INTERVAL clean steps double it again (never above the initial value).  A changed
-        scale is picked up by the next step; a recorded hipGraph is re-recorded (the scale is baked into it)."""
-        ev = self._flag_event
-        if ev is None or not ev.query():
-            return
-        self._flag_event = None
-        if float(self._flag_host[0]) != 0.0:
-            self.loss_scale = max(1.0, self.loss_scale * 0.5)
-            self._clean_steps = 0
-            if not self._warned_overflow:
-                self._warned_overflow = True
-                import warnings
+        """GradScaler's scale update at a fixed lag of LossScaler.LAG steps (identical on every rank).  A changed scale is
+        picked up by this very step; a recorded hipGraph is re-recorded (the scale is baked into it)."""
+        before = self.scaler.scale
+        if self.scaler.begin_step() and self.scaler.scale < before and not self._warned_overflow:
+            self._warned_overflow = True
+            import warnings
 
-                warnings.warn(f"LoraTrainer: non-finite fp16 gradients — the step was skipped and the loss scale "
-                              f"lowered to {self.loss_scale:g} (GradScaler semantics)")
-        else:
-            self._clean_steps += 1
-            if self._clean_steps >= self.GROWTH_INTERVAL and self.loss_scale < self._initial_scale:
-                self.loss_scale, self._clean_steps = min(self._initial_scale, self.loss_scale * 2.0), 0
+            warnings.warn(f"LoraTrainer: non-finite fp16 gradients — the step was skipped and the loss scale "
+                          f"lowered to {self.scaler.scale:g} (GradScaler semantics)")
 
     def _fingerprint(self):
         """Everything a recorded step has baked in besides the shapes: scalars passed as kernel arguments and the
@@ -490,23 +553,58 @@ class LoraTrainer:
                 tuple((l.linear.weight.data_ptr(), l.linear.weight._version) for l in layers), ff2)
 
     # -- one step ---------------------------------------------------------------------------------
-    def step(self, latents, noise, timesteps, encoder_hidden_states, *, with_prior_preservation=False,
-             prior_loss_weight=1.0, mask=None, seed: Optional[int] = None):
-        """latents fp32 [B,4,h,w] on the device, encoder_hidden_states [B,L,D].  Either pass `noise` (fp32, like
-        latents) and `timesteps` (int64 [B]) — the caller drew them, as the reference does — or pass None for both and
-        a `seed`: the step then draws them on the device (Philox keyed by (seed, optimizer step), identical on
-        every rank) inside the prologue kernel."""
+    def step(self, latents, noise, timesteps, encoder_hidden_states=None, *, with_prior_preservation=False,
+             prior_loss_weight=1.0, mask=None, seed: Optional[int] = None, input_ids=None):
+        """latents fp32 [B,4,h,w] on the device.  Conditioning: `encoder_hidden_states` [B,L,D] — or `input_ids` [B,L]
+        (int64), in which case the step itself runs `text_encoder(input_ids)[0]` as the reference's loop does
+        (train_lora_dreambooth.py:840); with a LoRA text encoder that is what makes the step recordable.  Noise: either
+        pass `noise` (fp32, like latents) and `timesteps` (int64 [B]) — the caller drew them, as the reference does — or
+        pass None for both and a `seed`: the step then draws them on the device (Philox keyed by (seed, optimizer step),
+        identical on every rank) inside the prologue kernel.  `mask`: raw [B,1,8h,8w] mask of cli_lora_pti.py:222-247."""
+        if (encoder_hidden_states is None) == (input_ids is None):
+            raise ValueError("pass exactly one of encoder_hidden_states and input_ids")
+        if input_ids is not None and self.text_encoder is None:
+            raise ValueError("input_ids given but the trainer has no text encoder")
         self._poll_overflow()
-        if self.capture_graph and mask is None and self.text_encoder is None:
-            return self._step_graph(latents, noise, timesteps, encoder_hidden_states, with_prior_preservation,
-                                    prior_loss_weight, seed)
-        return self._step_eager(latents, noise, timesteps, encoder_hidden_states, with_prior_preservation,
-                                prior_loss_weight, mask, seed, early_bucket=True)
+        recordable = not self.trains_text_encoder or input_ids is not None
+        if self.capture_graph and recordable:
+            return self._step_graph(latents, noise, timesteps, encoder_hidden_states, input_ids, mask,
+                                    with_prior_preservation, prior_loss_weight, seed)
+        return self._step_eager(latents, noise, timesteps, encoder_hidden_states, input_ids, with_prior_preservation,
+                                prior_loss_weight, mask, seed)
 
-    def _step_eager(self, latents, noise, timesteps, encoder_hidden_states, with_prior_preservation, prior_loss_weight,
-                    mask, seed, early_bucket):
-        """Host-launched step.  early_bucket=False sends the slab in ONE all-reduce after backward — the collective
-        sequence of a hipGraph step — so a rank whose graph recording failed stays matched with ranks that replay."""
+    def _conditioning(self, encoder_hidden_states, input_ids):
+        if input_ids is None:
+            return encoder_hidden_states.to(self.dtype)
+        if self.trains_text_encoder:
+            return self.text_encoder(input_ids)[0].to(self.dtype)
+        with torch.no_grad():  # frozen encoder: train_lora_dreambooth.py:608-609
+            return self.text_encoder(input_ids)[0].to(self.dtype)
+
+    def _forward_backward(self, noisy, target, timesteps, ehs, prior, prior_weight, raw_mask):
+        """UNet forward → fused loss → backward → batched factor gradients + fold.  Shared by both launch modes."""
+        pred = self.unet(noisy, timesteps, ehs).sample
+        rows = pred.shape[0]
+        n_inst, n_prior = (rows // 2, rows // 2) if prior else (rows, 0)
+        m = None
+        if raw_mask is not None:
+            m = nat.lora_mask_prepare(raw_mask, pred.shape[2], pred.shape[3])
+        pred_c = pred if pred.is_contiguous() else pred.contiguous()
+        loss, dpred = nat.ddpm_mse_fwd_bwd(pred_c, target, m, n_inst, n_prior, prior_weight, self.loss_scale)
+        pred_c.backward(dpred)
+        self.slab.flush()  # factor gradients of every layer that ran: batched launch + ordered fold into the slab
+        return loss
+
+    def _raw_mask(self, mask, latents):
+        if mask is None:
+            return None
+        rows, h, w = latents.shape[0], latents.shape[2], latents.shape[3]
+        return mask.to(self.device).reshape(rows, 1, h * 8, w * 8).float().contiguous()
+
+    def _step_eager(self, latents, noise, timesteps, encoder_hidden_states, input_ids, with_prior_preservation,
+                    prior_loss_weight, mask, seed):
+        """Host-launched step.  Exchange: two buckets with the early one overlapping backward where that is possible
+        (SlabExchange / _install_bucket_hook) — unless a recorded step was asked for (exchange.single)."""
         self.slab.zero_grad()
         self.slab.repack()  # packed compute-dtype factors follow the fp32 masters (also after external edits)
         if noise is None:
@@ -517,44 +615,28 @@ class LoraTrainer:
         else:
             noisy, target = nat.ddpm_add_noise(latents, noise, timesteps, self.sqrt_acp, self.sqrt_1macp, self.dtype,
                                                self.v_prediction)
-        if early_bucket:
-            self.exchange.arm()
-        pred = self.unet(noisy, timesteps, encoder_hidden_states.to(self.dtype)).sample
-        rows = pred.shape[0]
-        n_inst, n_prior = (rows // 2, rows // 2) if with_prior_preservation else (rows, 0)
-        m = None
-        if mask is not None:
-            raw = mask.to(self.device).reshape(rows, 1, pred.shape[2] * 8, pred.shape[3] * 8).float().contiguous()
-            m = nat.lora_mask_prepare(raw, pred.shape[2], pred.shape[3])
-        pred_c = pred if pred.is_contiguous() else pred.contiguous()
-        loss, dpred = nat.ddpm_mse_fwd_bwd(pred_c, target, m, n_inst, n_prior, prior_loss_weight, self.loss_scale)
-        pred_c.backward(dpred)
-        self.slab.flush()  # factor gradients of every layer that ran: batched launch + ordered fold into the slab
+        self.exchange.arm()
+        ehs = self._conditioning(encoder_hidden_states, input_ids)
+        loss = self._forward_backward(noisy, target, timesteps, ehs, with_prior_preservation, prior_loss_weight,
+                                      self._raw_mask(mask, latents))
         self.exchange.finish()
         self.opt.step(grad_mul=1.0 / (self.world * self.loss_scale))
         self._watch_overflow()
         self.slab.repack()  # forwards outside step() (sampling, evaluation, saving merged weights) see the new factors
         return loss
 
-
     # -- the same step with forward+backward replayed from a hipGraph -----------------------------------
     def _graph_body(self, st):
-        """What is captured: reads only static buffers, leaves the factor-gradient partials and the loss behind."""
+        """What is captured: reads only static buffers, leaves the gradient slab and the loss behind."""
         if st["draw"]:
             noisy, target = st["noisy"], st["target"]
         else:
             noisy, target = nat.ddpm_add_noise(st["latents"], st["noise"], st["timesteps"], self.sqrt_acp,
                                                self.sqrt_1macp, self.dtype, self.v_prediction)
-        pred = self.unet(noisy, st["timesteps"], st["ehs"]).sample
-        rows = pred.shape[0]
-        n_inst, n_prior = (rows // 2, rows // 2) if st["prior"] else (rows, 0)
-        pred_c = pred if pred.is_contiguous() else pred.contiguous()
-        loss, dpred = nat.ddpm_mse_fwd_bwd(pred_c, target, None, n_inst, n_prior, st["prior_weight"], self.loss_scale)
-        pred_c.backward(dpred)
-        self.slab.flush()
-        st["loss"] = loss
+        ehs = self._conditioning(st["ehs"], st["ids"])
+        st["loss"] = self._forward_backward(noisy, target, st["timesteps"], ehs, st["prior"], st["prior_weight"], st["mask"])
 
-    def _graph_inputs(self, st, latents, noise, timesteps, ehs, seed):
+    def _graph_inputs(self, st, latents, noise, timesteps, ehs, ids, mask, seed):
         if st["draw"]:
             if seed is None:
                 raise ValueError("pass noise and timesteps, or a seed for the on-device draw")
@@ -567,23 +649,34 @@ class LoraTrainer:
             st["latents"].copy_(latents)
             st["noise"].copy_(noise)
             st["timesteps"].copy_(timesteps)
-        st["ehs"].copy_(ehs)  # casts to the compute dtype
+        if ids is None:
+            st["ehs"].copy_(ehs)  # casts to the compute dtype
+        else:
+            st["ids"].copy_(ids)
+        if mask is not None:
+            st["mask"].copy_(self._raw_mask(mask, latents))
         self.slab.zero_grad()
         self.slab.repack()
 
-    def _step_graph(self, latents, noise, timesteps, ehs, prior, prior_weight, seed):
-        key = (tuple(latents.shape), tuple(ehs.shape), bool(prior), float(prior_weight), noise is None)
+    def _step_graph(self, latents, noise, timesteps, ehs, ids, mask, prior, prior_weight, seed):
+        cond_shape = tuple(ehs.shape) if ids is None else ("ids",) + tuple(ids.shape)
+        key = (tuple(latents.shape), cond_shape, bool(prior), float(prior_weight), noise is None, mask is not None)
         fp = self._fingerprint()
         st = self._graph
         if st is None or st["key"] != key or st["fp"] != fp:
             self._graph = st = None  # drop the old recording (and the operand buffers it pins) before making a new one
+            rows, h, w = latents.shape[0], latents.shape[2], latents.shape[3]
             st = {"key": key, "fp": fp, "draw": noise is None, "prior": bool(prior), "prior_weight": float(prior_weight),
                   "latents": torch.empty_like(latents, dtype=torch.float32),
                   "noise": torch.empty_like(latents, dtype=torch.float32),
                   "timesteps": torch.empty(latents.shape[0], dtype=torch.int64, device=self.device),
                   "noisy": torch.empty_like(latents, dtype=self.dtype), "target": torch.empty_like(latents, dtype=self.dtype),
-                  "ehs": torch.empty_like(ehs, dtype=self.dtype), "graph": None}
-            self._graph_inputs(st, latents, noise, timesteps, ehs, seed)
+                  "ehs": None if ids is not None else torch.empty_like(ehs, dtype=self.dtype),
+                  "ids": None if ids is None else torch.empty_like(ids, device=self.device),
+                  "mask": None if mask is None else torch.empty((rows, 1, h * 8, w * 8), dtype=torch.float32,
+                                                                device=self.device),
+                  "graph": None}
+            self._graph_inputs(st, latents, noise, timesteps, ehs, ids, mask, seed)
             try:
                 # warm up on a side stream (solver searches, lazy initialisation, allocator), then record
                 side = torch.cuda.Stream()
@@ -600,20 +693,19 @@ class LoraTrainer:
                 with torch.cuda.graph(g, capture_error_mode=mode):
                     self._graph_body(st)
                 st["graph"] = g
-            except Exception as exc:  # keep training: this trainer falls back to eager steps for good
+            except Exception as exc:  # keep training: this trainer falls back to host-launched steps for good
                 import warnings
 
-                warnings.warn(f"LoraTrainer: hipGraph capture failed ({exc!r}); continuing with eager steps")
+                warnings.warn(f"LoraTrainer: hipGraph capture failed ({exc!r}); continuing with host-launched steps")
                 self.capture_graph, self._graph = False, None
-                # THIS step still exchanges like a graph step (one all-reduce): peers may have recorded fine
-                return self._step_eager(latents, noise, timesteps, ehs, prior, prior_weight, None, seed,
-                                        early_bucket=False)
+                # exchange.single stays set: this rank keeps issuing the one whole-slab all-reduce its peers' replays issue
+                return self._step_eager(latents, noise, timesteps, ehs, ids, prior, prior_weight, mask, seed)
             self._graph = st
             # the warm-up passes each folded this step's gradients into the slab: clear it, then replay once so that
             # every step (including the first) is produced by the same recorded kernels
             self.slab.zero_grad()
         else:
-            self._graph_inputs(st, latents, noise, timesteps, ehs, seed)
+            self._graph_inputs(st, latents, noise, timesteps, ehs, ids, mask, seed)
         st["graph"].replay()
         self.exchange.finish()
         self.opt.step(grad_mul=1.0 / (self.world * self.loss_scale))

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LORA_HIP_ABI_VERSION 4
+#define LORA_HIP_ABI_VERSION 5
 
 enum lora_dtype { LORA_F32 = 0, LORA_F16 = 1, LORA_BF16 = 2 };
 
@@ -85,6 +85,12 @@ int lora_linear_fwd(const void* X, const void* W, const void* bias /* nullable *
                     const float* A, const float* B, const void* Apack, const void* Bpack, void* Y,
                     float* T_out, int64_t M, int K, int N, int r, float scale, int dtype,
                     void* stream);
+/* The same with optional split-K scratch (see lora_linear_bwd_input_ws / lora_gemm_workspace_bytes(M, K, N, dtype)):
+ * the 1280-wide projections at 1024 and 256 rows leave a third of the chip idle unless their contraction is cut. */
+int lora_linear_fwd_ws(const void* X, const void* W, const void* bias /* nullable */,
+                       const float* A, const float* B, const void* Apack, const void* Bpack, void* Y,
+                       float* T_out, int64_t M, int K, int N, int r, float scale, int dtype,
+                       void* workspace /* nullable */, int64_t ws_bytes, void* stream);
 
 /*
  * The same forward with the GEGLU gate of its caller folded into the epilogue — diffusers GEGLU.forward
@@ -128,12 +134,18 @@ int lora_linear_bwd_input(const void* dY, const void* Wt, const float* A, const 
                           const void* Apack, const void* Bpack, void* dX /* nullable */, float* U_out,
                           int64_t M, int K, int N, int r, float scale, int dtype, void* stream);
 /*
- * The same with caller-provided scratch for split-K: a long contraction on a grid too small for the chip (the GEGLU
- * `proj` backward: dX[1024,1280] = dY[1024,10240]·W — 80 output tiles, 160 K-steps) is cut into K-slices that store
- * fp32 partial tiles, and a second launch adds the slices in index order (deterministic), the bias and the rank-r term.
+ * The same with caller-provided scratch for split-K: a contraction on a grid too small for the chip (the GEGLU `proj`
+ * backward: dX[1024,1280] = dY[1024,10240]·W — 80 output tiles, 160 K-steps; the 1280-wide projections at 1024 and 256
+ * rows) is cut into K-slices inside ONE launch: a slice stores its fp32 partial tile, takes a ticket of the tile, and the
+ * workgroup that draws the last ticket adds the slices in index order (deterministic whoever arrives last) and runs the
+ * usual epilogue (rank-r term, bias, store).
  * lora_gemm_workspace_bytes(M, Kc, Nc, dtype) says how much scratch the contraction [M,Kc]·[Nc,Kc]ᵀ wants (0: the
- * library would not split it); the workspace is only used during the call's launches (stream-ordered), 16-byte aligned.
+ * library would not split it).  Layout: the first LORA_GEMM_WS_TICKET_BYTES bytes are the tiles' tickets — they must be
+ * ZERO when the call is made and are zero again when its launch has finished (so one buffer, zeroed once, serves every
+ * later call on the same stream) — the rest is uninitialised scratch.  16-byte aligned; used only by the call's launch
+ * (stream-ordered); two launches that may run concurrently need a workspace each.
  */
+#define LORA_GEMM_WS_TICKET_BYTES 4096
 int64_t lora_gemm_workspace_bytes(int64_t M, int Kc, int Nc, int dtype);
 int lora_linear_bwd_input_ws(const void* dY, const void* Wt, const float* A, const float* B,
                              const void* Apack, const void* Bpack, void* dX /* nullable */, float* U_out,
@@ -392,7 +404,7 @@ int attn_flash_bwd(const void* Q, const void* K, const void* V, const void* O, c
  * returns a substring of that name.  lora_prof_collect waits for the recorded events, returns the totals
  * and resets the recording.
  */
-#define LORA_PROF_KINDS 10
+#define LORA_PROF_KINDS 16
 typedef struct lora_prof_totals {
     int64_t launches[LORA_PROF_KINDS];
     double ms[LORA_PROF_KINDS];

@@ -77,3 +77,67 @@ def test_two_ranks_equal_one_rank_with_double_batch():
     assert single.exitcode == 0
     err = ((two - one).norm() / one.norm()).item()
     assert err < 1e-4, err
+
+
+def _run_overflow(rank, world, port, out):
+    """fp16, 2 ranks: rank 1's batch is poisoned with an inf at step 2 — after the SUM all-reduce BOTH ranks see a
+    non-finite slab, skip the step, and must lower their loss scale at the SAME later step (LossScaler's fixed lag); a rank
+    that moved one step earlier or later would mix gradients scaled by S and S/2 and the replicas would drift apart."""
+    import itertools
+
+    import diffusion_finetuning_amd as dfa
+    from diffusion_finetuning_amd import trainer as tr
+    from oracle import lora_oracle as orc
+    from tests.conftest import build_tiny_unet
+
+    torch.set_num_threads(2)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    unet = build_tiny_unet(seed=3).to(dev).half()
+    params, _ = dfa.inject_trainable_lora(unet, r=4)
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        for i, p in enumerate(itertools.chain(*params)):
+            if i % 2 == 0:
+                p.copy_((torch.randn(p.shape, generator=g) * 0.02).to(dev))
+    trainer = tr.LoraTrainer(unet, lr=1e-3, group_projections=False, loss_scale=256.0)
+    scales = []
+    for step in range(8):
+        latents, noise, ts, ctx = orc.synthetic_batch(step, 2 * world, 8, 6, 32)
+        sl = slice(rank * 2, (rank + 1) * 2)
+        lat = latents[sl].clone()
+        if step == 2 and rank == 1:
+            lat[0, 0, 0, 0] = float("inf")
+        if rank == 1:
+            torch.cuda.synchronize()  # the ranks' host/GPU timing differs on purpose: rank 1 always sees its flag copy landed
+        trainer.step(lat.to(dev), noise[sl].to(dev), ts[sl].to(dev), ctx[sl].to(dev))
+        if rank == 1:
+            torch.cuda.synchronize()
+        scales.append(trainer.loss_scale)
+    state = trainer.slab.params[: trainer.slab.numel].cpu()
+    assert torch.isfinite(state).all()
+    assert trainer.opt.skipped_steps() == 1 and trainer.opt.applied_steps() == 7
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (scales, state.numpy().copy()))
+    if rank == 0:
+        out.put(gathered)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_back_the_loss_scale_off_at_the_same_step():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run_overflow, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    gathered = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    (s0, p0), (s1, p1) = gathered
+    assert s0 == s1, (s0, s1)                                   # the same scale at every step on both ranks
+    assert s0 == [256.0] * 4 + [128.0] * 4, s0                  # step 2 overflowed → applied at the start of step 2 + LAG
+    assert (p0 == p1).all()                                     # and the replicas stayed bit-identical

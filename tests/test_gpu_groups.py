@@ -436,3 +436,141 @@ def test_full_size_fp16_step_vs_fp32_cpu_oracle(relerr, prior):
     agree = (((got - init_state) * (want - init_state)) > 0).float().mean().item()
     assert agree > 0.97, agree  # f16 compute: elements whose gradient is within ~2 % of the layer's rms may flip
     assert relerr(got, want) < 1e-3
+
+
+def _copy_frozen(ref_state, model):
+    model.load_state_dict({k.replace(".linear.", "."): v for k, v in ref_state.items()})
+
+
+def _check_update(got, want, init, grad, ref_grad, offsets, relerr, loss, ref_loss):
+    assert abs(loss - ref_loss) / abs(ref_loss) < 3e-3, (loss, ref_loss)
+    gn, rn = grad / grad.norm(), ref_grad / ref_grad.norm()
+    assert relerr(gn, rn) < 1.5e-2, relerr(gn, rn)
+    worst = max(relerr(gn[o:o + n], rn[o:o + n]) for o, n in offsets)
+    assert worst < 8e-2, worst
+    agree = (((got - init) * (want - init)) > 0).float().mean().item()
+    assert agree > 0.96, agree
+    assert relerr(got, want) < 1e-3
+
+
+def test_full_size_cfg5_sd21_768_rank16_v_prediction_step_vs_cpu_oracle(relerr):
+    """BASELINE config 5 at full size, per GPU: SD2.1-768-shaped UNet (heads of 64: 5/10/20/20, 1024-wide context, linear
+    proj_in/out), LoRA rank 16, batch 1, 96×96 latents (M = 9216 / 2304 / 576 / 144), v-prediction target — ONE f16 step
+    (grouped context K/V at rank 16, q/k/v ungrouped: 3·16 rank slots do not fit 16, both attention cores, gated GEGLU
+    epilogues) against the fp32 CPU oracle on the same weights and inputs: loss, gradient direction, LoRA update."""
+    import bench
+    from harness.unet import UNet2DConditionModel, sd21_768_config
+
+    torch.set_num_threads(bench.usable_cpus())
+
+    def make():
+        torch.manual_seed(0)
+        m = UNet2DConditionModel(sd21_768_config())
+        m.requires_grad_(False)
+        return m
+
+    ref = make()
+    ref_params, _ = orc.inject(ref, r=16)
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for i, p in enumerate(ref_params):
+            if i % 2 == 0:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.01)
+    init_state = orc.flat_params(ref_params).clone()
+    state = {k: v.clone() for k, v in ref.state_dict().items() if "lora_" not in k}
+    ref_losses = orc.train_steps(ref, ref_params, 1, 1, 96, 77, 1024, lr=1e-4, v_prediction=True)
+    ref_grad = torch.cat([p.grad.reshape(-1) for p in ref_params])
+    want = orc.flat_params(ref_params)
+    del ref
+
+    unet = make()
+    _copy_frozen(state, unet)
+    unet = unet.half().to(DEV)
+    params, _ = dfa.inject_trainable_lora(unet, r=16)
+    plist = list(itertools.chain(*params))
+    with torch.no_grad():
+        for p, rp in zip(plist, torch.split(init_state, [q.numel() for q in plist])):
+            p.copy_(rp.view(p.shape).to(DEV))
+    set_use_memory_efficient_attention_xformers(unet, True)
+    set_use_hip_geglu(unet, True)
+    trainer = tr.LoraTrainer(unet, lr=1e-4, v_prediction=True)
+    assert not trainer.slab.qkv_groups and trainer.slab.ctx_groups[0].G == 32 and trainer.slab.ctx_groups[0].K == 1024
+    assert trainer.slab.numel == 4 * 1246464 + 16 * 32 * 256  # r=16, and the 1024-wide (not 768) context side of 32 layers
+    lat, noise, ts, ctx = orc.synthetic_batch(0, 1, 96, 77, 1024)
+    loss = trainer.step(lat.to(DEV), noise.to(DEV), ts.to(DEV), ctx.to(DEV)).item()
+    assert not trainer.opt.overflowed()
+    _check_update(tr.flat_lora_state(unet).cpu(), want, init_state, trainer.slab.grads[: trainer.slab.numel].cpu(), ref_grad,
+                  trainer.slab.offsets, relerr, loss, ref_losses[0])
+
+
+def test_full_size_cfg3_unet_plus_clip_l_text_encoder_step_vs_cpu_oracle(relerr):
+    """BASELINE config 3 at full size: SD1.5-shaped UNet AND a CLIP-L-shaped text encoder (hidden 768, 12 layers, 12 heads,
+    MLP 3072, 77 positions; random init — no checkpoints offline), LoRA rank 8 on both (one --lora_rank,
+    train_lora_dreambooth.py:596-613), batch 4 at 64×64 latents, two learning rates (:659-676) — ONE f16 step, the step
+    running the text encoder itself from token ids (:840), against the fp32 CPU oracle loop."""
+    import bench
+    from harness.unet import UNet2DConditionModel, sd15_config
+    from transformers import CLIPTextConfig, CLIPTextModel
+
+    torch.set_num_threads(bench.usable_cpus())
+    ccfg = CLIPTextConfig(hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
+                          vocab_size=49408, max_position_embeddings=77, bos_token_id=49406, eos_token_id=49407, pad_token_id=1)
+
+    def make():
+        torch.manual_seed(0)
+        u = UNet2DConditionModel(sd15_config())
+        u.requires_grad_(False)
+        torch.manual_seed(2)
+        t = CLIPTextModel(ccfg)
+        t.requires_grad_(False)
+        return u, t
+
+    lr_u, lr_t, B = 1e-4, 5e-5, 4
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(2, 49000, (B, 77), generator=g)
+    ids[:, 0], ids[:, -1] = 49406, 49407
+    ref_unet, ref_te = make()
+    pu, _ = orc.inject(ref_unet, r=8)
+    pt, _ = orc.inject(ref_te, orc.TEXT_ENCODER_TARGETS, r=8)
+    params = pu + pt
+    with torch.no_grad():
+        for i, p in enumerate(params):
+            if i % 2 == 0:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.01)
+    init_state = orc.flat_params(params).clone()
+    u_state = {k: v.clone() for k, v in ref_unet.state_dict().items() if "lora_" not in k}
+    t_state = {k: v.clone() for k, v in ref_te.state_dict().items() if "lora_" not in k}
+    acp = orc.ddpm_alphas_cumprod()
+    latents, noise, ts, _ = orc.synthetic_batch(0, B, 64, 77, 768)
+    ehs = ref_te(ids)[0]
+    pred = ref_unet(orc.add_noise(latents, noise, ts, acp), ts, ehs).sample
+    ref_loss = orc.mse_loss(pred, noise)
+    ref_loss.backward()
+    grads = [p.grad for p in params]
+    orc.clip_grad_norm(grads, 1.0)
+    ref_grad = torch.cat([gr.reshape(-1) for gr in grads])
+    with torch.no_grad():
+        for i, (p, gr) in enumerate(zip(params, grads)):
+            orc.adamw_step(p, gr, torch.zeros_like(p), torch.zeros_like(p), 1, lr_u if i < len(pu) else lr_t)
+    want = orc.flat_params(params)
+    del ref_unet, ref_te, pred, ehs
+
+    unet, te = make()
+    _copy_frozen(u_state, unet)
+    _copy_frozen(t_state, te)
+    unet, te = unet.half().to(DEV), te.half().to(DEV)
+    gu, _ = dfa.inject_trainable_lora(unet, r=8)
+    gt, _ = dfa.inject_trainable_lora(te, dfa.TEXT_ENCODER_DEFAULT_TARGET_REPLACE, r=8)
+    plist = list(itertools.chain(*gu)) + list(itertools.chain(*gt))
+    assert len(plist) == len(params) == 2 * (144 + 48)
+    with torch.no_grad():
+        for p, rp in zip(plist, torch.split(init_state, [q.numel() for q in plist])):
+            p.copy_(rp.view(p.shape).to(DEV))
+    set_use_memory_efficient_attention_xformers(unet, True)
+    set_use_hip_geglu(unet, True)
+    trainer = tr.LoraTrainer(unet, te, lr=lr_u, lr_text=lr_t)
+    assert trainer.slab.numel == 2 * 1246464 + 48 * 8 * (768 + 768)  # 12.3 MB of fp32 gradients (BASELINE.md §4)
+    loss = trainer.step(latents.to(DEV), noise.to(DEV), ts.to(DEV), input_ids=ids.to(DEV)).item()
+    assert not trainer.opt.overflowed()
+    _check_update(trainer.slab.params[: trainer.slab.numel].cpu(), want, init_state,
+                  trainer.slab.grads[: trainer.slab.numel].cpu(), ref_grad, trainer.slab.offsets, relerr, loss, ref_loss.item())

@@ -80,7 +80,9 @@ SD_SHAPES = [  # (M, K, N, bias): the distinct LoRA GEMMs of SD1.5 at 512² / B=
 @pytest.mark.parametrize("r", [1, 4, 8, 16])
 def test_operator_against_oracle_sd_shapes(relerr, close, dtype, r):
     g = torch.Generator().manual_seed(100 + r)
-    for (M, K, N, bias) in SD_SHAPES[:: (2 if r in (1, 8) else 1)]:
+    # r = 1 and r = 8 run every other shape — plus, always, the CLIP-L projection (308,768,768): cfg-3 trains it at r = 8
+    shapes = SD_SHAPES if r in (4, 16) else sorted(set(SD_SHAPES[::2]) | {(308, 768, 768, True)}, key=SD_SHAPES.index)
+    for (M, K, N, bias) in shapes:
         x = torch.randn(M, K, generator=g).to(dtype)
         w = ((torch.rand(N, K, generator=g) * 2 - 1) / K ** 0.5).to(dtype)
         b = (torch.randn(N, generator=g) * 0.1).to(dtype) if bias else None
@@ -676,28 +678,76 @@ def test_pack_factors_and_partial_reduce_entry_points(relerr):
 
 
 def test_hot_path_kernels_are_deterministic():
-    """No atomics anywhere on the path: repeated launches on the same inputs are bit-identical (the stock PyTorch
-    convolution/attention backward kernels around them are not, so this is asserted per kernel, not per step)."""
+    """No float atomics anywhere on the path: repeated launches on the same inputs are bit-identical (the stock PyTorch
+    convolution/attention backward kernels around them are not, so this is asserted per kernel, not per step).  The
+    shapes cover the unsplit ring kernel and the split-K launches (1280-wide projections at 1024 / 256 rows, the GEGLU
+    `proj` backward): there the tile's LAST ARRIVER adds the K-slices — in index order whoever it is, so the result may
+    not depend on the arrival order, which differs from launch to launch."""
     g = torch.Generator().manual_seed(8)
-    M, K, N, r = 4096, 640, 640, 4
-    x = torch.randn(M, K, generator=g).to(DEV).half()
-    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV).half()
-    a, b = (torch.randn(r, K, generator=g) / r).to(DEV), (torch.randn(N, r, generator=g) * 0.05).to(DEV)
-    dy = torch.randn(M, N, generator=g).to(DEV).half()
-    wt = w.t().contiguous()
-    runs = []
-    for _ in range(3):
-        y, t = nat.lora_linear_fwd(x, w, None, a, b, 1.0)
-        dx, u = nat.lora_linear_bwd_input(dy, wt, a, b, 1.0, True)
-        ga, gb = torch.zeros(r, K, device=DEV), torch.zeros(N, r, device=DEV)
-        nat.lora_linear_bwd_params(dy, x, t, u, ga, gb, 1.0)
-        p = torch.randn(M * 16, generator=torch.Generator().manual_seed(1)).to(DEV)
-        norm = torch.zeros(4, device=DEV)
-        nat.lora_grad_sqnorm(p, 1.0, norm)
-        runs.append((y, t, dx, u, ga, gb, norm.clone()))
-    for other in runs[1:]:
-        for first, again in zip(runs[0], other):
-            assert torch.equal(first, again)
+    for (M, K, N, r) in ((4096, 640, 640, 4), (1024, 1280, 1280, 4), (256, 1280, 1280, 16), (1024, 10240, 1280, 4),
+                         (1000, 1280, 3840, 12)):
+        x = torch.randn(M, K, generator=g).to(DEV).half()
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV).half()
+        a, b = (torch.randn(r, K, generator=g) / r).to(DEV), (torch.randn(N, r, generator=g) * 0.05).to(DEV)
+        dy = torch.randn(M, N, generator=g).to(DEV).half()
+        wt = w.t().contiguous()
+        runs = []
+        for _ in range(4):
+            y, t = nat.lora_linear_fwd(x, w, None, a, b, 1.0)
+            dx, u = nat.lora_linear_bwd_input(dy, wt, a, b, 1.0, True)
+            ga, gb = torch.zeros(r, K, device=DEV), torch.zeros(N, r, device=DEV)
+            nat.lora_linear_bwd_params(dy, x, t, u, ga, gb, 1.0)
+            p = torch.randn(M * 16, generator=torch.Generator().manual_seed(1)).to(DEV)
+            norm = torch.zeros(4, device=DEV)
+            nat.lora_grad_sqnorm(p, 1.0, norm)
+            runs.append((y, t, dx, u, ga, gb, norm.clone()))
+        for other in runs[1:]:
+            for first, again in zip(runs[0], other):
+                assert torch.equal(first, again), (M, K, N)
+
+
+def test_split_k_inside_the_gemm_launch(close):
+    """Contractions on grids too small for the chip are cut into K-slices INSIDE one launch (last-arriver reduction,
+    csrc/lora_gemm.hip): against float64 on the shapes the plan splits, with bias, ragged row counts and every rank class;
+    the workspace's ticket header must be zero again afterwards (the next launch relies on it), and the same call without
+    a workspace (unsplit) must agree to rounding."""
+    g = torch.Generator().manual_seed(21)
+    split_seen = 0
+    for (M, K, N, r, bias) in ((1024, 3840, 1280, 12, True), (256, 3840, 1280, 8, False), (1000, 5120, 1280, 16, True),
+                               (1024, 10240, 1280, 4, False), (200, 5120, 640, 1, True), (77, 10240, 320, 4, False),
+                               (1024, 1280, 1280, 4, True)):
+        x = torch.randn(M, K, generator=g).half()
+        w = ((torch.rand(N, K, generator=g) * 2 - 1) / K ** 0.5).half()
+        bvec = (torch.randn(N, generator=g) * 0.1).half() if bias else None
+        down = (torch.randn(r, K, generator=g) / r).half().float()
+        up = (torch.randn(N, r, generator=g) * 0.05).half().float()
+        s = 0.7
+        y_ref = orc.lora_linear_forward(x.double(), w.double(), None if bvec is None else bvec.double(), down.double(),
+                                        up.double(), s)
+        t_ref = x.double() @ down.double().t()
+        xd, wd = x.to(DEV), w.to(DEV)
+        bd = None if bvec is None else bvec.to(DEV)
+        nbytes = nat.lib().lora_gemm_workspace_bytes(M, K, N, nat.dtype_code(torch.float16))
+        split_seen += int(nbytes > 0)
+        y, T = nat.lora_linear_fwd(xd, wd, bd, down.to(DEV), up.to(DEV), s)
+        close(y, y_ref, 2e-3, (M, K, N, r, "y"))
+        close(T, t_ref, 1e-3, (M, K, N, r, "t"))
+        if nbytes > 0:
+            ws = next(iter(nat._splitk_ws.values()))
+            header = ws.view(torch.int32)[: 1024]
+            assert int(header.abs().max().item()) == 0, "ticket header not left at zero"
+            # the unsplit launch of the same problem (no workspace handed over)
+            packs = nat.lora_pack_factors(down.to(DEV), up.to(DEV), torch.float16)
+            y0 = torch.empty_like(y)
+            t0 = torch.empty_like(T)
+            st = nat.lib().lora_linear_fwd(xd.data_ptr(), wd.data_ptr(), 0 if bd is None else bd.data_ptr(),
+                                           down.to(DEV).data_ptr(), up.to(DEV).data_ptr(), packs[0].data_ptr(),
+                                           packs[1].data_ptr(), y0.data_ptr(), t0.data_ptr(), M, K, N, r, s,
+                                           nat.dtype_code(torch.float16), nat._stream(xd))
+            assert st == 0
+            close(y, y0, 1e-3, (M, K, N, r, "split vs unsplit"))
+            close(T, t0, 1e-5, (M, K, N, r, "split vs unsplit T"))
+    assert split_seen >= 5, "the plan no longer splits the shapes this test was written for"
 
 
 def test_cfg3_text_encoder_lora_rank8(relerr):
@@ -819,9 +869,12 @@ def test_noise_prologue_matches_philox_oracle(relerr):
     assert torch.isfinite(l0).all()
 
 
-def test_cfg3_unet_plus_text_encoder_training_step(relerr, tiny_unet_factory):
+@pytest.mark.parametrize("mode", ["ehs", "ids", "ids-graph"])
+def test_cfg3_unet_plus_text_encoder_training_step(relerr, tiny_unet_factory, mode):
     """BASELINE config 3 end to end (--train_text_encoder, train_lora_dreambooth.py:608-621,659-676): UNet LoRA r=4 and
-    CLIP LoRA r=8 in ONE slab with two learning rates; attn2 to_k/to_v now need dX (the text encoder trains)."""
+    CLIP LoRA r=8 in ONE slab with two learning rates; attn2 to_k/to_v now need dX (the text encoder trains).
+    `ehs`: the caller runs the text encoder and hands over its output; `ids`: the step runs it (train_lora_dreambooth.py:840);
+    `ids-graph`: that step recorded into a hipGraph and replayed — the recording must really exist."""
     from transformers import CLIPTextConfig, CLIPTextModel
 
     ccfg = CLIPTextConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2,
@@ -854,7 +907,7 @@ def test_cfg3_unet_plus_text_encoder_training_step(relerr, tiny_unet_factory):
     params = pu + pt
     m = [torch.zeros_like(p) for p in params]
     v = [torch.zeros_like(p) for p in params]
-    trainer = tr.LoraTrainer(unet, te, lr=lr_u, lr_text=lr_t)
+    trainer = tr.LoraTrainer(unet, te, lr=lr_u, lr_text=lr_t, capture_graph=mode == "ids-graph")
     assert trainer.slab.model_ranges[1][0] == trainer.slab.model_ranges[0][1] > 0
     for step in range(3):
         latents, noise, ts, _ = orc.synthetic_batch(step, 2, 8, 6, 32)
@@ -868,8 +921,11 @@ def test_cfg3_unet_plus_text_encoder_training_step(relerr, tiny_unet_factory):
         with torch.no_grad():
             for i, (p, gr, mm, vv) in enumerate(zip(params, grads, m, v)):
                 orc.adamw_step(p, gr, mm, vv, step + 1, lr_u if i < len(pu) else lr_t)
-        ehs_g = te(ids.to(DEV))[0]
-        trainer.step(latents.to(DEV), noise.to(DEV), ts.to(DEV), ehs_g)
+        if mode == "ehs":
+            trainer.step(latents.to(DEV), noise.to(DEV), ts.to(DEV), te(ids.to(DEV))[0])
+        else:
+            trainer.step(latents.to(DEV), noise.to(DEV), ts.to(DEV), input_ids=ids.to(DEV))
+    assert (trainer._graph is not None) == (mode == "ids-graph")
     n_u = sum(p.numel() for p in pu)
     got = trainer.slab.params[: trainer.slab.numel].cpu()
     want = orc.flat_params(params)
@@ -1213,7 +1269,7 @@ def test_cfg1_full_size_sd15_fp32_trajectory_vs_cpu_oracle(relerr):
     import bench
     from harness.unet import UNet2DConditionModel, sd15_config
 
-    steps = 4
+    steps = 10  # BASELINE.json configs[0]: "10 steps on CPU reference path" (also bench.py's cpu_baseline.cfg1 workload)
     n_threads = bench.usable_cpus()
     torch.set_num_threads(n_threads)
 
@@ -1256,3 +1312,49 @@ def test_cfg1_full_size_sd15_fp32_trajectory_vs_cpu_oracle(relerr):
     assert relerr(torch.tensor(losses), torch.tensor(ref_losses)) < 1e-3
     assert relerr(got, want) < 1e-3
     assert relerr(got - init_state, want - init_state) < 2e-2  # the 4-step UPDATE itself, not just the state
+
+
+def test_masked_step_recorded_into_a_hipgraph(tiny_unet_factory, relerr):
+    """cli_lora_pti.py:222-247 masked loss inside the recorded step (the raw mask is a static input like the latents): the
+    replayed trajectory is the host-launched one, and both follow the CPU oracle's masked loop."""
+    def run(graph):
+        unet = tiny_unet_factory(seed=5).to(DEV)
+        params, _ = dfa.inject_trainable_lora(unet, r=4)
+        _warm(list(itertools.chain(*params)), 11, 0.02)
+        trainer = tr.LoraTrainer(unet, lr=1e-3, capture_graph=graph)
+        losses = []
+        for step in range(4):
+            lat, noise, ts, ctx = orc.synthetic_batch(step, 2, 8, 6, 32)
+            g = torch.Generator().manual_seed(50 + step)
+            mask = (torch.rand(2, 1, 64, 64, generator=g) > 0.4).float()
+            losses.append(trainer.step(lat.to(DEV), noise.to(DEV), ts.to(DEV), ctx.to(DEV), mask=mask))
+        assert (trainer._graph is not None) == graph
+        return tr.flat_lora_state(unet).cpu(), torch.stack(losses).reshape(-1).cpu()
+
+    want, lw = run(False)
+    got, lg = run(True)
+    assert relerr(got, want) < 2e-5 and relerr(lg, lw) < 2e-5, (relerr(got, want), relerr(lg, lw))
+    # the CPU oracle's masked loop
+    ref = tiny_unet_factory(seed=5)
+    ref_params, _ = orc.inject(ref, r=4)
+    _warm(ref_params, 11, 0.02)
+    acp = orc.ddpm_alphas_cumprod()
+    m = [torch.zeros_like(p) for p in ref_params]
+    v = [torch.zeros_like(p) for p in ref_params]
+    ref_losses = []
+    for step in range(4):
+        lat, noise, ts, ctx = orc.synthetic_batch(step, 2, 8, 6, 32)
+        g = torch.Generator().manual_seed(50 + step)
+        mask = (torch.rand(2, 1, 64, 64, generator=g) > 0.4).float()
+        for p in ref_params:
+            p.grad = None
+        pred = ref(orc.add_noise(lat, noise, ts, acp), ts, ctx).sample
+        loss = orc.masked_mse_loss(pred, noise, mask)
+        loss.backward()
+        ref_losses.append(loss.item())
+        grads = [p.grad for p in ref_params]
+        orc.clip_grad_norm(grads, 1.0)
+        with torch.no_grad():
+            for p, gr, mm, vv in zip(ref_params, grads, m, v):
+                orc.adamw_step(p, gr, mm, vv, step + 1, 1e-3)
+    assert relerr(lg, torch.tensor(ref_losses)) < 1e-3 and relerr(got, orc.flat_params(ref_params)) < 1e-3
