@@ -216,6 +216,14 @@ def set_use_memory_efficient_attention_xformers(module: nn.Module, valid: bool) 
     Modules or calls outside the kernels' envelope (e.g. the VAE's 512-wide single head) keep deferring to their own
     forward, like the reference turns xformers off per block when its probe fails (xformers_utils.py:46-60)."""
     set_use_hip_attention(module, bool(valid))
+    # The switch a reference trainer flips is the only hook an UNCHANGED trainer ever calls, so it also turns on the fused
+    # GEGLU gate of the feed-forward blocks under `module` (set_use_hip_geglu: same arithmetic as diffusers' GEGLU.forward /
+    # FeedForward.forward, inside the `proj` LoRA launch and the ff.net.2 backward launch); modules without a GEGLU — the
+    # VAE the trainers also pass here — are untouched.  DFA_XFORMERS_SWITCH_GEGLU=0 keeps the two switches separate.
+    import os
+
+    if os.environ.get("DFA_XFORMERS_SWITCH_GEGLU", "1") != "0":
+        set_use_hip_geglu(module, bool(valid))
 
 
 def test_xformers_backwards(size: int) -> bool:

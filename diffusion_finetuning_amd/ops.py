@@ -90,6 +90,8 @@ class _LoraLinearFn(torch.autograd.Function):
         ctx.x_dtype = x.dtype
         ctx.factor_dtypes = (down.dtype, up.dtype)
         ctx.grad_sink = grad_sink
+        ctx.auto_sink = _auto_sink_for(down, up) if grad_sink is None else None
+        ctx.params = (down, up) if ctx.auto_sink is not None else None
         return y2.view(*x.shape[:-1], N)
 
     @staticmethod
@@ -103,6 +105,91 @@ class _LoraLinearFn(torch.autograd.Function):
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         return (*_lora_backward(ctx, x2, a, b, t, dy2), None, None, None, None, None, None)
+
+
+class _AutoSink:
+    """Drop-in mode (no trainer.LoraSlab): where the factor gradients of a plain `loss.backward()` go.
+
+    An unchanged reference trainer (train_lora_dreambooth.py:877) never builds a slab, so every wrapped layer used to launch
+    its own two reductions (+ workspace, fold and two accumulations: ~7 small launches × 144 layers, latency-bound).  Here the
+    backward of a layer only DEFERS its two problems; when the autograd engine finishes the pass (`queue_callback`, the hook
+    DDP's reducer uses) ONE `lora_grad_batched` call launches all of them, one fold sums the row-block partials, and the
+    results are handed to the Parameters' `.grad` (set, or accumulated into an existing one — gradient accumulation keeps
+    working).  Not used when a process group is alive (DDP all-reduces what AccumulateGrad hands it: those steps keep the
+    per-layer launches that return real gradient tensors), when a Parameter carries hooks, or with DFA_DEFER_GRADS=0.
+    `torch.autograd.grad(loss, lora_params)` is not a `.backward()`: it sees None for deferred inputs and raises unless
+    allow_unused is set — use DFA_DEFER_GRADS=0 for such callers."""
+
+    def __init__(self, device):
+        self.device = device
+        self.items = []
+        self.armed = False
+        self.partials = None
+
+    def defer(self, dy2, x2, t, u, scale, down, up, dtypes):
+        self.items.append((dy2, x2, t, u, scale, down, up, dtypes))
+        if not self.armed:
+            self.armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+
+    def flush(self):
+        items, self.items, self.armed = self.items, [], False
+        if not items:
+            return
+        offs, total = [], 0
+        for dy2, x2, t, u, *_ in items:
+            n = t.shape[1] * (dy2.shape[1] + x2.shape[1])
+            offs.append(total)
+            total += n
+        stride = (total + 3) // 4 * 4
+        if self.partials is None or self.partials.shape[1] < stride:
+            self.partials = torch.empty((nat.GRAD_MAX_BLOCKS, stride), dtype=torch.float32, device=self.device)
+        part, pstride = self.partials, self.partials.shape[1]
+        grads = torch.empty(stride, dtype=torch.float32, device=self.device)
+        base = part.data_ptr()
+        by_dtype, rows = {}, []
+        for off, (dy2, x2, t, u, scale, _, _, _) in zip(offs, items):
+            M, N = dy2.shape
+            K, r = x2.shape[1], t.shape[1]
+            probs = by_dtype.setdefault(dy2.dtype, [])
+            probs.append(nat.grad_problem(dy2, 0, N, N, t, 0, r, r, [base + 4 * off], r, False, pstride, M, scale))
+            probs.append(nat.grad_problem(x2, 0, K, K, u, 0, r, r, [base + 4 * (off + N * r)], r, True, pstride, M, scale))
+            rows.append([off, r * (N + K), nat.grad_row_blocks(M), 0])
+        for dt, probs in by_dtype.items():
+            nat.lora_grad_batched(probs, dt, self.device)
+        table = torch.tensor(rows, dtype=torch.int64).to(self.device)
+        nat.lora_fold_partials(table, len(rows), max(r_[1] for r_ in rows), part, pstride, grads, False)
+        for off, (dy2, x2, t, u, _, down, up, dtypes) in zip(offs, items):
+            N, K, r = dy2.shape[1], x2.shape[1], t.shape[1]
+            for p, g, dt in ((up, grads[off:off + N * r].view(N, r), dtypes[1]),
+                             (down, grads[off + N * r:off + r * (N + K)].view(r, K), dtypes[0])):
+                if dt != torch.float32:
+                    g = g.to(dt)
+                if p.grad is None:
+                    p.grad = g
+                else:
+                    p.grad += g
+
+
+_auto_sinks = {}
+
+
+def _auto_sink_for(down, up):
+    """The drop-in sink of the tensors' device, or None when deferring is not safe for these Parameters (see _AutoSink)."""
+    import os
+
+    import torch.distributed as dist
+
+    if os.environ.get("DFA_DEFER_GRADS", "1") == "0" or (dist.is_available() and dist.is_initialized()):
+        return None
+    for p in (down, up):
+        if not isinstance(p, torch.nn.Parameter) or not p.is_leaf or p._backward_hooks or \
+                getattr(p, "_post_accumulate_grad_hooks", None):
+            return None
+    sink = _auto_sinks.get(down.device)
+    if sink is None:
+        sink = _auto_sinks[down.device] = _AutoSink(down.device)
+    return sink
 
 
 def _lora_backward(ctx, x2, a, b, t, dy2):
@@ -120,6 +207,10 @@ def _lora_backward(ctx, x2, a, b, t, dy2):
             # trainer mode: nothing is launched here — the two reductions join the slab's batched gradient launch
             # after backward, their row-block partials land in the model-wide partial slab (= the RCCL buffer's twin)
             sink.defer_layer(dy2, x2, t, u, ctx.scale)
+        elif ctx.auto_sink is not None:
+            # drop-in mode: the two reductions join ONE batched launch at the end of this backward pass (_AutoSink)
+            down, up = ctx.params
+            ctx.auto_sink.defer(dy2, x2, t, u, ctx.scale, down, up, ctx.factor_dtypes)
         else:
             g_down = torch.zeros_like(a)
             g_up = torch.zeros_like(b)
@@ -168,6 +259,8 @@ class _LoraGegluFn(torch.autograd.Function):
         ctx.x_dtype = x.dtype
         ctx.factor_dtypes = (down.dtype, up.dtype)
         ctx.grad_sink = grad_sink
+        ctx.auto_sink = _auto_sink_for(down, up) if grad_sink is None else None
+        ctx.params = (down, up) if ctx.auto_sink is not None else None
         return out.view(*x.shape[:-1], w.shape[0] // 2)
 
     @staticmethod
@@ -213,6 +306,8 @@ class _LoraProjGatedFn(torch.autograd.Function):
         ctx.x_dtype = x.dtype
         ctx.factor_dtypes = (down.dtype, up.dtype)
         ctx.grad_sink = grad_sink
+        ctx.auto_sink = _auto_sink_for(down, up) if grad_sink is None else None
+        ctx.params = (down, up) if ctx.auto_sink is not None else None
         N = w.shape[0]
         out = out.view(*x.shape[:-1], N // 2)
         ctx.mark_non_differentiable(out)

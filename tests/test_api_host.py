@@ -279,3 +279,10 @@ def test_attention_hook_patches_and_restores_without_a_gpu():
     assert torch.equal(blk(x, ctx), want)
     assert xu.set_use_hip_geglu(blk, False) == 1
     assert all("forward" not in m.__dict__ for m in blk.modules())
+    # the reference's switch is the only hook an unchanged trainer calls: it turns on the attention cores AND the fused gate
+    xu.set_use_memory_efficient_attention_xformers(blk, True)
+    hooked = sorted(type(m).__name__ for m in blk.modules() if "forward" in m.__dict__)
+    assert hooked == ["CrossAttention", "CrossAttention", "FeedForward", "GEGLU"], hooked
+    assert torch.equal(blk(x, ctx), want)
+    xu.set_use_memory_efficient_attention_xformers(blk, False)
+    assert all("forward" not in m.__dict__ for m in blk.modules())

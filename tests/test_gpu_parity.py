@@ -1358,3 +1358,38 @@ def test_masked_step_recorded_into_a_hipgraph(tiny_unet_factory, relerr):
             for p, gr, mm, vv in zip(ref_params, grads, m, v):
                 orc.adamw_step(p, gr, mm, vv, step + 1, 1e-3)
     assert relerr(lg, torch.tensor(ref_losses)) < 1e-3 and relerr(got, orc.flat_params(ref_params)) < 1e-3
+
+
+def test_drop_in_backward_defers_factor_gradients_into_one_batched_launch(tiny_unet_factory, relerr, monkeypatch):
+    """An unchanged trainer's `loss.backward()` (no LoraSlab): the per-layer factor-gradient launches are deferred and go
+    out as ONE lora_grad_batched call when the autograd engine finishes the pass (ops._AutoSink); `.grad` of every LoRA
+    Parameter must equal what the per-layer launches produce (DFA_DEFER_GRADS=0), accumulate over two backward passes, and
+    survive optimizer.zero_grad(set_to_none=True)."""
+    unet = tiny_unet_factory(seed=2).to(DEV)
+    params, _ = dfa.inject_trainable_lora(unet, r=4)
+    plist = list(itertools.chain(*params))
+    _warm(plist, 5, 0.02)
+    lat, noise, ts, ctx = orc.synthetic_batch(0, 2, 8, 6, 32)
+    calls = []
+    real = nat.lora_grad_batched
+    monkeypatch.setattr(nat, "lora_grad_batched", lambda probs, dt, dev: (calls.append(len(probs)), real(probs, dt, dev))[1])
+
+    def backward():
+        pred = unet(lat.to(DEV), ts.to(DEV), ctx.to(DEV)).sample
+        dfa.ddpm_mse_loss(pred, noise.to(DEV)).backward()
+
+    backward()
+    n_layers = len(plist) // 2
+    assert calls == [2 * n_layers]  # every layer's two reductions in one call
+    deferred = [p.grad.clone() for p in plist]
+    backward()  # accumulation into existing .grad
+    for p, g in zip(plist, deferred):
+        assert relerr(p.grad, 2 * g) < 1e-5
+    for p in plist:
+        p.grad = None
+    monkeypatch.setenv("DFA_DEFER_GRADS", "0")
+    del calls[:]
+    backward()
+    assert calls == []  # per-layer launches
+    for p, g in zip(plist, deferred):
+        assert relerr(p.grad, g) < 1e-5, relerr(p.grad, g)
