@@ -14,7 +14,7 @@ _lib = None
 _lock = threading.Lock()
 
 ABI_VERSION = 5
-PROF_KINDS = 16
+PROF_KINDS = 17
 
 _DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 

@@ -480,8 +480,8 @@ int launch_ctx(const CtxArgs& a, const CtxPlan& pl, hipStream_t stream) {
     LORA_LAUNCH_CHECK();
     const int64_t total = (int64_t)a.B * a.Tk * a.H * a.d;
     const unsigned blocks = (unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-    // (the ordered sum of the chunk partials: its time is recorded as kind "other", it carries no algorithmic bytes)
-    LORA_LAUNCH(PK_OTHER, attn_ctx_reduce_kernel<T>, dim3(blocks), dim3(256), 0, stream, a.part, static_cast<T*>(a.dK),
+    // (the ordered sum of the chunk partials: its time is charged to the backward's kind, it carries no algorithmic bytes)
+    LORA_LAUNCH(PK_CTX_BWD, attn_ctx_reduce_kernel<T>, dim3(blocks), dim3(256), 0, stream, a.part, static_cast<T*>(a.dK),
                 static_cast<T*>(a.dV), a.B, a.Tk, a.H, a.d, pl.chunks, pl.slices, NKF * 16, DF * 16, a.ld_dk);
     LORA_LAUNCH_CHECK();
     return LORA_OK;

@@ -96,7 +96,8 @@ enum ProfKernel {
     PK_GRAD_R4, PK_GRAD_R8, PK_GRAD_R16, PK_MSE, PK_OTHER,
     PK_GATED_BWD,                                  // frozen ff.net.2 backward-input GEMM with the GEGLU gate's backward (f-4)
     PK_FLASH_FWD, PK_FLASH_DQ, PK_FLASH_DKDV,      // long-context attention core (f-4)
-    PK_CTX_FWD, PK_CTX_BWD,                        // short-context attention core (f-4)
+    PK_CTX_FWD, PK_CTX_BWD,                        // short-context attention core (f-4; BWD includes its ordered chunk sum)
+    PK_GEMM_SPLITK,                                // fused GEMM launches whose contraction is cut into K-slices (in-launch combine)
     PK_COUNT
 };
 static_assert(PK_COUNT == LORA_PROF_KINDS, "lora_hip.h LORA_PROF_KINDS out of date");

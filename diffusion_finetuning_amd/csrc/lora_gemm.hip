@@ -52,6 +52,8 @@ struct GemmParams {
     float scale;
     int tiles_m, tiles_n;
     int col_major;  // 1: consecutive tiles walk down M inside a column tile (an XCD then owns a slice of Bm)
+    int xcd_m;      // > 1: the 8 XCDs form an xcd_m × (8/xcd_m) grid over the tile grid, each XCD owns a RECTANGLE of tiles
+                    // (both splits exact) — an XCD's L2 then fetches |Am|/xcd_m + |Bm|·xcd_m/8 instead of all of one operand
     int64_t lda;    // row stride of Am in elements (>= Kc: Am may be a column slice of a wider buffer)
     // Grouped launches (several LoRA layers that share Am in one launch; nullptr = one layer):
     //  MAIN:  tile_part[tn] = part | first << 16 for every column tile — the tile multiplies with the part's own
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
     // Pull every kernel argument into SGPRs now: one scalar-load round trip instead of two dependent ones.
     asm volatile("" ::"s"(p.Am), "s"(p.Bm), "s"(p.bias), "s"(p.Fp), "s"(p.Qp), "s"(p.C), "s"(p.P), "s"(p.M), "s"(p.Kc),
                  "s"(p.Nc), "s"(p.scale), "s"(p.tiles_m), "s"(p.tiles_n), "s"(p.col_major), "s"(p.lda), "s"(p.tile_part),
-                 "s"(p.part_table), "s"(p.splitk), "s"(p.steps_per_slice), "s"(p.ws_c), "s"(p.ws_p), "s"(p.tickets));
+                 "s"(p.part_table), "s"(p.splitk), "s"(p.steps_per_slice), "s"(p.ws_c), "s"(p.ws_p), "s"(p.tickets), "s"(p.xcd_m));
     int tile, slice = 0;
     {
         const int S = p.splitk > 1 ? p.splitk : 1;
@@ -202,10 +204,23 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
     // Which operand should stay inside one XCD's L2?  Row-major tile order keeps a row panel of Am there and makes
     // every XCD stream all of Bm; column-major order keeps a slice of Bm there and streams Am instead.  The host
     // picks the order that re-fetches the SMALLER operand eight times (col_major when Bm is the bigger one).
-    const unsigned inner = p.col_major ? p.tiles_m : p.tiles_n;  // tiles along the fast direction
-    const unsigned t_slow = (unsigned)tile / inner, t_fast = (unsigned)tile - t_slow * inner;
-    const int tm = p.col_major ? t_fast : t_slow;
-    const int tn = p.col_major ? t_slow : t_fast;
+    int tm, tn;
+    if (p.xcd_m > 1) {
+        // 2-D XCD ownership (square-ish problems: neither operand is small enough to be re-fetched by all eight L2s).
+        // Block id → (XCD, slot) as above; the XCD's rectangle is rm × rn tiles, walked column by column.
+        const int xn = 8 / p.xcd_m;
+        const unsigned rm = p.tiles_m / p.xcd_m, rn = p.tiles_n / xn;
+        const unsigned xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const unsigned ln = slot / rm, lm = slot - ln * rm;
+        tm = (xcd / xn) * rm + lm;
+        tn = (xcd % xn) * rn + ln;
+        tile = tm * p.tiles_n + tn;
+    } else {
+        const unsigned inner = p.col_major ? p.tiles_m : p.tiles_n;  // tiles along the fast direction
+        const unsigned t_slow = (unsigned)tile / inner, t_fast = (unsigned)tile - t_slow * inner;
+        tm = p.col_major ? t_fast : t_slow;
+        tn = p.col_major ? t_slow : t_fast;
+    }
     STAMP(12);
     const int64_t m0 = (int64_t)tm * BM;
     const int n0 = tn * BN;
@@ -1036,6 +1051,24 @@ int launch_tile(GemmParams p, hipStream_t stream) {
     p.tiles_n = MAIN ? (p.Nc + BN - 1) / BN : (p.part_table ? p.tiles_n : 1);  // skinny grouped: tiles_n = parts
     static const int order_env = [] { const char* e = getenv("LORA_FORCE_COLMAJOR"); return e ? atoi(e) : -1; }();
     p.col_major = order_env >= 0 ? order_env : (MAIN && (int64_t)p.Nc > p.M ? 1 : 0);
+    p.xcd_m = 1;
+    if (MAIN && p.splitk <= 1 && p.tile_part == nullptr) {
+        // Which XCD grid re-fetches the fewest operand bytes?  An xm × xn grid (xm·xn = 8) makes the eight L2s fetch
+        // xn·|Am| + xm·|Bm| in total; (8,1) and (1,8) are the row- / column-major runs above (any tile counts), the 2-D
+        // grids need exact splits.  Only square-ish problems (the 1280-wide layers at 1024 / 256 rows) pick one.
+        static const int x2d_env = [] { const char* e = getenv("LORA_XCD2D"); return e ? atoi(e) : 1; }();
+        const double am = (double)p.M * p.Kc, bm = (double)p.Nc * p.Kc;
+        double best = p.col_major ? 8.0 * am + bm : am + 8.0 * bm;
+        for (int xm = 2; xm <= 4 && x2d_env; xm *= 2) {
+            const int xn = 8 / xm;
+            if (p.tiles_m % xm != 0 || p.tiles_n % xn != 0) continue;
+            const double cost = xn * am + xm * bm;
+            if (cost < 0.8 * best) {
+                best = cost;
+                p.xcd_m = xm;
+            }
+        }
+    }
     constexpr int lds = gemm_lds_bytes<BM, BN, T, MAIN, STG, NW, WM>();
     auto kern = lora_gemm_kernel<T, BM, BN, MAIN, STG, NW, WM>;
     if (lds > 48 * 1024) {
@@ -1046,11 +1079,12 @@ int launch_tile(GemmParams p, hipStream_t stream) {
     constexpr int prof_id = MAIN ? (NW == 8 ? PK_GEMM_256x128 : (BM == 128 ? PK_GEMM_128x128 : PK_GEMM_64x64))
                                  : (BM == 128 ? PK_SKINNY_128 : PK_SKINNY_64);
     const int S = p.splitk > 1 ? p.splitk : 1;
+    const int kind = S > 1 ? (int)PK_GEMM_SPLITK : prof_id;
     if (S > 1) {  // workspace = [tickets | fp32 tiles | P tiles] (splitk_ws_bytes)
         p.ws_c = reinterpret_cast<float*>(reinterpret_cast<char*>(p.tickets) + kTicketBytes);
         p.ws_p = p.ws_c + (int64_t)p.tiles_m * p.tiles_n * S * (BM * BN);
     }
-    LORA_LAUNCH(prof_id, kern, dim3(p.tiles_m * p.tiles_n * S), dim3(NW * 64), lds, stream, p);
+    LORA_LAUNCH(kind, kern, dim3(p.tiles_m * p.tiles_n * S), dim3(NW * 64), lds, stream, p);
     LORA_LAUNCH_CHECK();
     return LORA_OK;
 }
@@ -1142,6 +1176,13 @@ int launch_pipe(const GemmParams& p_in, hipStream_t stream) {
         bool w160 = (p.Nc % 160) == 0 && (p.Nc % 128) != 0 && tiles160 >= 128;
         if (forced_tile() == 7) w160 = (p.Nc % 160) == 0;
         if (forced_tile() == 0 || forced_tile() == 2 || forced_tile() == 1) w160 = false;  // 1: the 128|64-square rules only
+        // ... and when that grid has fewer than 384 tiles (the 320-wide projections at 16384 rows: 256 tiles, one per CU),
+        // 64×160 tiles double the count — two workgroups per CU overlap each other's fixed phases: 16384×320×320
+        // 12.1 → 11.4 µs, 16384×1280→320 27.9 → 27.0 (round 3; wider outputs lose: 16384×320→1280 26.4 → 30.6)
+        bool half160 = w160 && tiles160 < 384;
+        if (forced_tile() == 8) half160 = (p.Nc % 160) == 0;
+        if (forced_tile() == 7) half160 = false;
+        if (half160) return launch_tile<T, 64, 160, true, 2, 4>(p, stream);
         if (w160) return launch_tile<T, 128, 160, true, 2, 4>(p, stream);
         // 128×128 grids of 128..255 tiles leave a third of the CUs idle (4096×640×640: 160 tiles): 64×128 tiles double the
         // count at 3/4 of the flops per staged byte — 12.5 → 11.0 µs there, 32.8 → 28.2 µs at K = 2560
@@ -1152,6 +1193,8 @@ int launch_pipe(const GemmParams& p_in, hipStream_t stream) {
         // grids too small for 128-row tiles, measured with the weights COLD (tools/gemm_bench.py --cold-read: in the model every
         // frozen weight comes from HBM): 64×128 tiles behind a 3-stage ring (two workgroups per CU, two K-steps in flight)
         // for 64..127-tile grids — 1024×1280×1280: 17.3 → 15.0 µs, the grouped q/k/v backward at 1024 rows 39 → 34 µs
+        // (round 3: the same tile behind a 4- or 5-stage ring — one workgroup per CU, as these 160-workgroup grids have anyway —
+        //  is SLOWER, 15.4 → 16.0 → 16.3 µs: a lone workgroup is not waiting on prefetch depth)
         if (!big && tiles128 >= 64 && (p.Nc % 128) == 0 && stg_env == 0 && forced_tile() < 0)
             return launch_tile<T, 64, 128, true, 3, 4>(p, stream);
     }

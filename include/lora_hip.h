@@ -404,7 +404,7 @@ int attn_flash_bwd(const void* Q, const void* K, const void* V, const void* O, c
  * returns a substring of that name.  lora_prof_collect waits for the recorded events, returns the totals
  * and resets the recording.
  */
-#define LORA_PROF_KINDS 16
+#define LORA_PROF_KINDS 17
 typedef struct lora_prof_totals {
     int64_t launches[LORA_PROF_KINDS];
     double ms[LORA_PROF_KINDS];

@@ -10,19 +10,19 @@ tag=${1:-r02}
 out=gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-run() { name=$1; shift; echo "[prof $name] $(date +%H:%M:%S) $*"; timeout -k 10 500 "$@" > "$out/$name.log" 2>&1; echo "[prof $name] rc=$?"; }
-run trace   rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline
-run fetch   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof --no-graph
-run write   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof --no-graph
-run mfma    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$out/pmc_mfma" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof --no-graph
+run() { name=$1; shift; echo "[prof $name] $(date +%H:%M:%S) $*"; timeout -k 10 700 "$@" > "$out/$name.log" 2>&1; echo "[prof $name] rc=$?"; }
+run trace   rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra
+run fetch   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-prof --no-graph
+run write   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-prof --no-graph
+run mfma    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$out/pmc_mfma" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-prof --no-graph
 t=$(ls "$out"/trace/*/*_kernel_trace.csv | head -1)
 f=$(ls "$out"/pmc_fetch/*/*_counter_collection.csv | head -1)
 w=$(ls "$out"/pmc_write/*/*_counter_collection.csv | head -1)
 m=$(ls "$out"/pmc_mfma/*/*_counter_collection.csv | head -1)
 mkdir -p "$out/summary"
-python3 tools/summarize_profile.py trace "$t" 4 "$out/summary/${tag}_timed_region_kernel_stats.csv" > /dev/null
+python3 tools/summarize_profile.py trace "$t" 9 "$out/summary/${tag}_timed_region_kernel_stats.csv" > /dev/null
 cp "$(ls "$out"/trace/*/*_kernel_stats.csv | head -1)" "$out/summary/${tag}_rocprofv3_kernel_stats_full_process.csv"
-python3 tools/summarize_profile.py shapes "$t" 4 > "$out/summary/${tag}_inmodel_launch_classes.txt"
+python3 tools/summarize_profile.py shapes "$t" 9 > "$out/summary/${tag}_inmodel_launch_classes.txt"
 python3 tools/summarize_profile.py pmc "$f" "$w" "$out/summary/${tag}_pmc_traffic.json" "$m" > /dev/null
 # the plain bench line LAST, with the fresh PMC summary in place, so that its roofline.traffic is this run's measurement
 cp "$out/summary/${tag}_pmc_traffic.json" profiles/

@@ -18,11 +18,16 @@ import sys
 
 
 def short(name):
-    m = re.search(r"(lora_\w+kernel|ddpm_mse_kernel|add_noise_kernel|noise_prologue_kernel|reduce_partials_kernel|pack_factors\w*|grad_sqnorm_kernel|adamw_kernel)", name)
+    m = re.search(r"(lora_\w+kernel|attn_\w+kernel|ddpm_mse_kernel|add_noise_kernel|noise_prologue_kernel|reduce_partials_kernel|pack_factors\w*|grad_sqnorm_kernel|adamw_kernel)", name)
     if not m:
         return name[:80]
     t = re.search(r"I(DF16_|DF16b|f)(?:Li(\d+)E)?(?:Li(\d+)E)?(?:Lb(\d)E)?(?:Lb(\d)E)?", name)
-    return m.group(1) + ("<" + ",".join(x for x in t.groups() if x) + ">" if t else "")
+    out = m.group(1) + ("<" + ",".join(x for x in t.groups() if x) + ">" if t else "")
+    # the fused GEMM's remaining template arguments: ring depth and the GEGLU-gate form (0 none, 1 forward, 2 backward)
+    g = re.search(r"lora_gemm_kernelI(?:DF16_|DF16b|f)Li\d+ELi\d+ELb\dELi(\d+)ELi\d+ELi\d+ELi(\d+)E", name)
+    if g:
+        out = out[:-1] + f",s{g.group(1)},g{g.group(2)}>"
+    return out
 
 
 def _step_start(name):  # the first hot-path kernel of a train step: the noise prologue (device draw) or add_noise (host draw)
@@ -58,7 +63,7 @@ def pmc(fetch, write, out, mfma=None):
     def load(path, counter):
         agg = collections.defaultdict(lambda: [0, 0.0])
         for r in csv.DictReader(open(path)):
-            if r["Counter_Name"] == counter and ("lora_" in r["Kernel_Name"] or "ddpm" in r["Kernel_Name"]):
+            if r["Counter_Name"] == counter and any(t in r["Kernel_Name"] for t in ("lora_", "ddpm", "attn_")):
                 a = agg[short(r["Kernel_Name"])]
                 a[0] += 1
                 a[1] += float(r["Counter_Value"])
@@ -93,7 +98,7 @@ def shapes(path, warmup):
     agg = collections.defaultdict(list)
     for r in rows:
         if int(r["Start_Timestamp"]) >= t0 and ("lora_" in r["Kernel_Name"] or "attn_" in r["Kernel_Name"] or "geglu" in r["Kernel_Name"]):
-            name = re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", r["Kernel_Name"])[:46]
+            name = short(r["Kernel_Name"])[:46]
             key = (name, int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])), int(r.get("Grid_Size_Y", 1) or 1), int(r["LDS_Block_Size"]))
             agg[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     print(f"{'kernel':46s} {'blocks':>7s} {'gy':>4s} {'lds':>7s} {'n/step':>7s} {'avg us':>8s} {'min':>7s} {'max':>7s} {'us/step':>8s}")
