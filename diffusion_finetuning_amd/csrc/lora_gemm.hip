@@ -800,41 +800,50 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
                 // (row, chunk): it loads the h and g chunks of Y = [h | g] (p.C2, read-only) and writes the two halves of
                 //     dY[:, :F] = dout·gelu(g),   dY[:, F:] = dout·h·gelu'(g)        (p.C)
                 // — the arithmetic of geglu_bwd_kernel on the same values; dout itself never goes to memory.
-                static_assert(FASTC && EP == 1, "the gate epilogue reads the whole C tile from one ring buffer");
-                constexpr int NST = ROWS * CPR / NT;
-                static_assert(NST % 2 == 0, "two register batches");
+                // (Per pass of ROWS rows; a chunk count that does not divide over the threads runs its last trip on clamped
+                //  indices with the stores predicated — loads are never under a per-lane condition.)
+                static_assert(FASTC, "the gate epilogue reads the C tile from a ring buffer");
+                constexpr int TOT = ROWS * CPR;
+                constexpr int NST = (TOT + NT - 1) / NT;
+                constexpr int H0 = (NST + 1) / 2;  // two register batches
                 const T* Yg = static_cast<const T*>(p.C2);
                 const int F = p.gateF;
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb) {
-                    Chunk<T> dv[NST / 2], hv[NST / 2], gv[NST / 2];
+                    const int first = hb == 0 ? 0 : H0, cnt = hb == 0 ? H0 : NST - H0;
+                    Chunk<T> dv[H0], hv[H0], gv[H0];
 #pragma unroll
-                    for (int i = 0; i < NST / 2; ++i) {
-                        const int idx = tid + (hb * (NST / 2) + i) * NT;
-                        const int row = idx / CPR, ch = idx - row * CPR;
-                        int64_t m = m0 + row;
-                        if (m > p.M - 1) m = p.M - 1;  // rows past the end: loaded from a valid row, never stored
-                        const T* yrow = Yg + m * (2 * (int64_t)F) + n0 + ch * VEC;
-                        hv[i] = *reinterpret_cast<const Chunk<T>*>(yrow);
-                        gv[i] = *reinterpret_cast<const Chunk<T>*>(yrow + F);
-                        dv[i] = *reinterpret_cast<const Chunk<T>*>(sC + row * SC_STRIDE + ch * 16);
+                    for (int i = 0; i < H0; ++i) {
+                        if (i < cnt) {
+                            int idx = tid + (first + i) * NT;
+                            if (TOT % NT != 0 && idx > TOT - 1) idx = TOT - 1;
+                            const int row = idx / CPR, ch = idx - row * CPR;
+                            int64_t m = m0 + ep * ROWS + row;
+                            if (m > p.M - 1) m = p.M - 1;  // rows past the end: loaded from a valid row, never stored
+                            const T* yrow = Yg + m * (2 * (int64_t)F) + n0 + ch * VEC;
+                            hv[i] = *reinterpret_cast<const Chunk<T>*>(yrow);
+                            gv[i] = *reinterpret_cast<const Chunk<T>*>(yrow + F);
+                            dv[i] = *reinterpret_cast<const Chunk<T>*>(sC + row * SC_STRIDE + ch * 16);
+                        }
                     }
 #pragma unroll
-                    for (int i = 0; i < NST / 2; ++i) {
-                        const int idx = tid + (hb * (NST / 2) + i) * NT;
-                        const int row = idx / CPR, ch = idx - row * CPR;
-                        const int64_t m = m0 + row;
-                        Chunk<T> dh, dg;
+                    for (int i = 0; i < H0; ++i) {
+                        if (i < cnt) {
+                            const int idx = tid + (first + i) * NT;
+                            const int row = idx / CPR, ch = idx - row * CPR;
+                            const int64_t m = m0 + ep * ROWS + row;
+                            Chunk<T> dh, dg;
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) {
-                            const float g = to_f32<T>(gv[i].v[e]), d = to_f32<T>(dv[i].v[e]);
-                            dh.v[e] = from_f32<T>(d * gelu_f<T>(g));
-                            dg.v[e] = from_f32<T>(d * to_f32<T>(hv[i].v[e]) * gelu_grad_f<T>(g));
-                        }
-                        if (m < p.M) {
-                            T* drow = Cg + m * (2 * (int64_t)F) + n0 + ch * VEC;
-                            *reinterpret_cast<Chunk<T>*>(drow) = dh;
-                            *reinterpret_cast<Chunk<T>*>(drow + F) = dg;
+                            for (int e = 0; e < VEC; ++e) {
+                                const float g = to_f32<T>(gv[i].v[e]), d = to_f32<T>(dv[i].v[e]);
+                                dh.v[e] = from_f32<T>(d * gelu_f<T>(g));
+                                dg.v[e] = from_f32<T>(d * to_f32<T>(hv[i].v[e]) * gelu_grad_f<T>(g));
+                            }
+                            if (idx < TOT && m < p.M) {
+                                T* drow = Cg + m * (2 * (int64_t)F) + n0 + ch * VEC;
+                                *reinterpret_cast<Chunk<T>*>(drow) = dh;
+                                *reinterpret_cast<Chunk<T>*>(drow + F) = dg;
+                            }
                         }
                     }
                 }
@@ -843,15 +852,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
             if constexpr (GATE == 1) {
                 // thread = (row, 16-B chunk of the h half) and the chunk of g behind it: y leaves as it is (when a backward
                 // pass will want it), out = h·gelu(g) from the SAME rounded values the separate gate kernel would read
-                static_assert(FASTC && EP == 1, "the gate epilogue reads the whole C tile from one ring buffer");
-                constexpr int HC = CPR / 2;         // chunks per half row
-                constexpr int NG = ROWS * HC / NT;  // (row, chunk) pairs per thread
+                static_assert(FASTC, "the gate epilogue reads the C tile from a ring buffer");
+                constexpr int HC = CPR / 2;                 // chunks per half row
+                constexpr int TOT = ROWS * HC;
+                constexpr int NG = (TOT + NT - 1) / NT;     // (row, chunk) pairs per thread (last trip clamped / predicated)
                 T* Og = static_cast<T*>(p.C2);
                 const int F = p.gateF;
                 Chunk<T> hv[NG], gv[NG];
 #pragma unroll
                 for (int i = 0; i < NG; ++i) {
-                    const int idx = tid + i * NT;
+                    int idx = tid + i * NT;
+                    if (TOT % NT != 0 && idx > TOT - 1) idx = TOT - 1;
                     const int row = idx / HC, ch = idx - row * HC;
                     hv[i] = *reinterpret_cast<const Chunk<T>*>(sC + row * SC_STRIDE + ch * 16);
                     gv[i] = *reinterpret_cast<const Chunk<T>*>(sC + row * SC_STRIDE + (HC + ch) * 16);
@@ -861,9 +872,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
                     for (int i = 0; i < NG; ++i) {
                         const int idx = tid + i * NT;
                         const int row = idx / HC, ch = idx - row * HC;
-                        const int64_t m = m0 + row;
+                        const int64_t m = m0 + ep * ROWS + row;
                         const int col = tn * (BN / 2) + ch * VEC;
-                        if (m < p.M) {
+                        if (idx < TOT && m < p.M) {
                             *reinterpret_cast<Chunk<T>*>(Cg + m * p.Nc + col) = hv[i];
                             *reinterpret_cast<Chunk<T>*>(Cg + m * p.Nc + F + col) = gv[i];
                         }
@@ -873,11 +884,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
                 for (int i = 0; i < NG; ++i) {
                     const int idx = tid + i * NT;
                     const int row = idx / HC, ch = idx - row * HC;
-                    const int64_t m = m0 + row;
+                    const int64_t m = m0 + ep * ROWS + row;
                     Chunk<T> o;
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) o.v[e] = from_f32<T>(to_f32<T>(hv[i].v[e]) * gelu_f<T>(to_f32<T>(gv[i].v[e])));
-                    if (m < p.M) *reinterpret_cast<Chunk<T>*>(Og + m * F + tn * (BN / 2) + ch * VEC) = o;
+                    if (idx < TOT && m < p.M) *reinterpret_cast<Chunk<T>*>(Og + m * F + tn * (BN / 2) + ch * VEC) = o;
                 }
                 continue;
             }
@@ -1089,10 +1100,27 @@ int launch_tile(GemmParams p, hipStream_t stream) {
     return LORA_OK;
 }
 
-// GEGLU-gated forward: always the 128×128 two-stage ring kernel (a tile = 64 h columns + their 64 g columns).
-template <typename T>
-int launch_gate(GemmParams p, hipStream_t stream) {
-    constexpr int BM = 128, BN = 128;
+// Column-tile width of the big launches.  Every SD width is a multiple of 128 AND of 160, so both tiles are exact; a
+// 128×160 tile costs ≈ 1.2× a 128×128 one and the chip holds 512 of either (two workgroups per CU), so the grid with fewer,
+// fatter tiles wins wherever the 128-wide grid leaves its last round mostly empty: 1024×1280→2·5120 is 640 tiles of 128 (two
+// rounds, the second a quarter full) or 512 tiles of 160 (ONE round).  `gated`: the measured rule of the gated launches
+// (tools/gemm_bench.py --geglu --cold-read with LORA_GATE_BN=128|160, µs 128 → 160; forward: 16384 rows 65.1 → 67.1,
+// 4096 rows 60.2 → 51.0, 1024 rows 57.0 → 39.1, 256 rows 27.1 → 29.6; backward: 53.1 → 53.6, 41.0 → 35.9, 40.4 → 36.8,
+// 30.1 → 34.7): 160 for grids of 257..2047 128-wide tiles.  Ungated launches use the round-count model only.
+int gate_tile_width(int64_t tiles_m, int cols, bool gated) {
+    static const int env = [] { const char* e = getenv("LORA_GATE_BN"); return e ? atoi(e) : 0; }();
+    if (cols % 160 != 0) return 128;
+    if (env == 128 || env == 160) return env;
+    const int64_t t128 = tiles_m * (cols / 128), t160 = tiles_m * (cols / 160);
+    if (gated) return t128 > 256 && t128 < 2048 ? 160 : 128;
+    const double c128 = (double)((t128 + 511) / 512), c160 = 1.25 * (double)((t160 + 511) / 512);
+    return c160 < c128 ? 160 : 128;
+}
+
+// GEGLU-gated forward: the two-stage ring kernel, a tile = BN/2 h columns + their BN/2 g columns.
+template <typename T, int BN>
+int launch_gate_bn(GemmParams p, hipStream_t stream) {
+    constexpr int BM = 128;
     p.tiles_m = (int)((p.M + BM - 1) / BM);
     p.tiles_n = p.gateF / (BN / 2);
     p.col_major = (int64_t)p.Nc > p.M ? 1 : 0;
@@ -1105,11 +1133,17 @@ int launch_gate(GemmParams p, hipStream_t stream) {
     LORA_LAUNCH_CHECK();
     return LORA_OK;
 }
-
-// GEGLU backward in the epilogue of dout = dZ·W2: 128×128 tiles over [M, F].
 template <typename T>
-int launch_gate_bwd(GemmParams p, hipStream_t stream) {
-    constexpr int BM = 128, BN = 128;
+int launch_gate(GemmParams p, hipStream_t stream) {
+    // (the h / g halves of a tile are column runs of 64 resp. 80: both divide every SD hidden width)
+    if (gate_tile_width((p.M + 127) / 128, 2 * p.gateF, true) == 160 && p.gateF % 80 == 0) return launch_gate_bn<T, 160>(p, stream);
+    return launch_gate_bn<T, 128>(p, stream);
+}
+
+// GEGLU backward in the epilogue of dout = dZ·W2: 128-row tiles over [M, F].
+template <typename T, int BN>
+int launch_gate_bwd_bn(GemmParams p, hipStream_t stream) {
+    constexpr int BM = 128;
     p.tiles_m = (int)((p.M + BM - 1) / BM);
     p.tiles_n = p.Nc / BN;
     p.col_major = (int64_t)p.Nc > p.M ? 1 : 0;
@@ -1121,6 +1155,11 @@ int launch_gate_bwd(GemmParams p, hipStream_t stream) {
     LORA_LAUNCH(PK_GATED_BWD, kern, dim3(p.tiles_m * p.tiles_n), dim3(256), lds, stream, p);
     LORA_LAUNCH_CHECK();
     return LORA_OK;
+}
+template <typename T>
+int launch_gate_bwd(GemmParams p, hipStream_t stream) {
+    if (gate_tile_width((p.M + 127) / 128, p.Nc, true) == 160) return launch_gate_bwd_bn<T, 160>(p, stream);
+    return launch_gate_bwd_bn<T, 128>(p, stream);
 }
 
 int forced_tile() {  // tuning knob for tools/gemm_bench.py only
@@ -1197,6 +1236,11 @@ int launch_pipe(const GemmParams& p_in, hipStream_t stream) {
         //  is SLOWER, 15.4 → 16.0 → 16.3 µs: a lone workgroup is not waiting on prefetch depth)
         if (!big && tiles128 >= 64 && (p.Nc % 128) == 0 && stg_env == 0 && forced_tile() < 0)
             return launch_tile<T, 64, 128, true, 3, 4>(p, stream);
+    }
+    if constexpr (sizeof(T) == 2) {
+        // chip-filling grids whose width divides by 128 AND 160: the tile whose grid wastes less of its last round
+        if (big && tiles128 >= 256 && forced_tile() < 0 && stg_env == 0 && gate_tile_width((p.M + 127) / 128, p.Nc, false) == 160)
+            return launch_tile<T, 128, 160, true, 2, 4>(p, stream);
     }
     if (big) {
         // (a 3-stage ring on grids of <= 256 tiles — one workgroup per CU anyway — was measured: no gain, 12.8 → 13.6 µs on

@@ -30,6 +30,10 @@ def _case(M, K, F, r, bias, dtype, seed=0):
     (256, 1280, 5120, 16, True),    # mid block, rank 16
     (129, 64, 64, 1, False),        # one K-step, one column tile, no bias
     (4096, 320, 1280, 8, True),
+    # grids where the 128×160 gated tile (80 h + 80 g columns, C tile in two passes) is the cheaper one: 640 tiles of 128
+    # would need two rounds on the chip, 512 tiles of 160 one (csrc/lora_gemm.hip: gate_tile_width); with a ragged row count
+    (1024, 128, 5120, 4, True),
+    (1000, 64, 5120, 16, False),
 ])
 def test_gated_forward_equals_the_two_launches_it_replaces_and_float64(close, dtype, M, K, F, r, bias):
     x, w, b, a, up = _case(M, K, F, r, bias, dtype)
@@ -168,7 +172,8 @@ def test_geglu_hook_routes_proj_through_the_gated_kernel_and_backpropagates(clos
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("M,Nz,F", [(1024, 320, 1280), (300, 640, 2560), (256, 1280, 5120), (129, 64, 128)])
+@pytest.mark.parametrize("M,Nz,F", [(1024, 320, 1280), (300, 640, 2560), (256, 1280, 5120), (129, 64, 128),
+                                    (4096, 64, 2560), (4000, 128, 2560)])  # the last two: 128×160 tiles (two store passes)
 def test_gate_backward_in_the_epilogue_of_the_following_linear_layers_backward(close, dtype, M, Nz, F):
     """`geglu_linear_bwd`: dY = gate-backward(dZ·W2, Y) in one launch.  Bit-identical to the library's own two steps (the same
     GEMM kernel without a gate, then geglu_gate_bwd on the rounded dout), and close to float64 autograd of

@@ -2,7 +2,7 @@
 # In-model A/B of an environment knob on ONE box: tools/ab_env.sh VAR valueA valueB  → two alternating bench runs each
 var=$1; a=$2; b=$3
 for v in $a $b $a $b; do
-env $var=$v python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/ab_env.log 2> gpurun_out/ab_env.err
+env $var=$v python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra > gpurun_out/ab_env.log 2> gpurun_out/ab_env.err
 python - <<P
 import json
 d=json.loads(open("gpurun_out/ab_env.log").read().strip().splitlines()[-1])
