@@ -9,7 +9,7 @@ import threading
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "liblora_hip.so")
+_LIB_PATH = os.environ.get("DFA_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "liblora_hip.so")  # (DFA_LIB_PATH: dev A/B builds)
 _lib = None
 _lock = threading.Lock()
 

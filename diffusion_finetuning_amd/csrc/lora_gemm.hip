@@ -335,6 +335,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
         const char* sF = st + OFF_F;
         if constexpr (!F32) {
             using Frag = typename Mfma<T>::Frag;
+            // (round 3, measured: issuing ALL fragment reads of the K-step up front, both 32-wide halves, so that the MFMAs wait
+            //  on counted lgkmcnt instead of the lgkmcnt(0) hipcc puts in front of every MFMA group here, changes nothing —
+            //  1024×1280×1280 15.5 / 15.4 / 15.4 µs for none / small tiles / all tiles, every other shape within 1 %: the
+            //  lone-workgroup main loop is not paced by exposed LDS latency)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const int chunk = ks * 4 + lq;
@@ -1087,7 +1091,7 @@ int launch_tile(GemmParams p, hipStream_t stream) {
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (attr != hipSuccess) return LORA_E_LAUNCH;
     }
-    constexpr int prof_id = MAIN ? (NW == 8 ? PK_GEMM_256x128 : (BM == 128 ? PK_GEMM_128x128 : PK_GEMM_64x64))
+    constexpr int prof_id = MAIN ? (BM >= 256 ? PK_GEMM_256x128 : (BM == 128 ? PK_GEMM_128x128 : PK_GEMM_64x64))
                                  : (BM == 128 ? PK_SKINNY_128 : PK_SKINNY_64);
     const int S = p.splitk > 1 ? p.splitk : 1;
     const int kind = S > 1 ? (int)PK_GEMM_SPLITK : prof_id;
@@ -1234,6 +1238,8 @@ int launch_pipe(const GemmParams& p_in, hipStream_t stream) {
         // for 64..127-tile grids — 1024×1280×1280: 17.3 → 15.0 µs, the grouped q/k/v backward at 1024 rows 39 → 34 µs
         // (round 3: the same tile behind a 4- or 5-stage ring — one workgroup per CU, as these 160-workgroup grids have anyway —
         //  is SLOWER, 15.4 → 16.0 → 16.3 µs: a lone workgroup is not waiting on prefetch depth)
+        // (also measured on this grid, round 3: the same tile as ONE 8-wave workgroup — 4×2 waves, two per SIMD instead of
+        //  one — 15.1 vs 15.2 µs behind 3 stages, 19.2 behind 2: neither the wave count nor a ring deeper than 3 moves it)
         if (!big && tiles128 >= 64 && (p.Nc % 128) == 0 && stg_env == 0 && forced_tile() < 0)
             return launch_tile<T, 64, 128, true, 3, 4>(p, stream);
     }
