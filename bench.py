@@ -625,6 +625,14 @@ def main():
             roof["all_fused_gemm_launches"] = {"launches_per_step": sum(v["launches"] for v in gemms) / args.steps,
                                                "ms_per_step": gt / args.steps, "hbm_frac": gb / gt / 1e6 / HBM_PEAK_GBS,
                                                "mfma_frac": gf / gt / 1e9 / MFMA_PEAK_TFLOPS[args.dtype]}
+            roof["fused_gemm_classes"] = {k: {"launches_per_step": v["launches"] / args.steps, "ms_per_step": v["ms"] / args.steps,
+                                              "hbm_frac": v["bytes"] / v["ms"] / 1e6 / HBM_PEAK_GBS,
+                                              "mfma_frac": v["flops"] / v["ms"] / 1e9 / MFMA_PEAK_TFLOPS[args.dtype]}
+                                          for k, v in lora.items() if k.startswith("lora_gemm_kernel")}
+            roof["note"] = ("`kernel` is the LoRA kind with the largest total time.  Through round 2 that was the 128-row tile class; "
+                            "since round 3 the 30 launches/step of the 320-wide projections run on 64x160 tiles and the split-K launches "
+                            "are a kind of their own, so the 64-row class is the largest — compare rounds with `all_fused_gemm_launches` "
+                            "(every fused forward / dX launch, whatever its tile) and `fused_gemm_classes`, not across class boundaries")
             # step level: every §8(d) kernel against the time the algorithmic bytes need at the HBM peak
             tot_b = sum(v["bytes"] for v in lora.values()) / args.steps
             tot_ms = sum(v["ms"] for v in lora.values()) / args.steps
