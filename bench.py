@@ -219,9 +219,9 @@ def measured_traffic(kernel_name, dtype):
         prefixes = [f"lora_gemm_kernel<DF16_,{m.group(1)},{bn},{1 if m.group(3) == 'true' else 0}" for bn in m.group(2).split("|")]
     else:
         prefixes = [kernel_name.split("<")[0]]
-    # (",g2>" = the gated frozen ff.net.2 backward GEMM: a kind of its own, not part of any LoRA class)
+    # (",g2" = the gated frozen ff.net.2 backward GEMM and "splitk" = the split-K instantiations: kinds of their own)
     entries = [v for k, v in table.items() if isinstance(v, dict) and any(k.startswith(p) for p in prefixes)
-               and ",g2>" not in k and "traffic_bytes_per_launch" in v]
+               and ",g2" not in k and "splitk" not in k and "traffic_bytes_per_launch" in v]
     n = sum(e.get("dispatches", 1) for e in entries)
     return sum(e["traffic_bytes_per_launch"] * e.get("dispatches", 1) for e in entries) / n if n else None
 

@@ -142,7 +142,9 @@ template <int BM, int BN, typename T, bool MAIN, int STG, int NW, int WM> conste
 
 // STG: LDS ring depth of the DMA pipeline (2 or 3); 0 selects the register-staged fallback loop.
 // NW waves as WM row waves × NW/WM column waves; every wave owns a (BM/WM) × (BN·WM/NW) piece of the tile.
-template <typename T, int BM, int BN, bool MAIN, int STG, int NW, int WM, int GATE = 0>  // GATE: 0 none, 1 GEGLU forward, 2 GEGLU backward
+// SPLITK: the launch cuts its contraction into K-slices (in-launch combine, below) — instantiations of their own, so that the
+// unsplit kernels carry none of that code and profilers can tell the two apart by name
+template <typename T, int BM, int BN, bool MAIN, int STG, int NW, int WM, int GATE = 0, bool SPLITK = false>  // GATE: 0 none, 1 GEGLU forward, 2 GEGLU backward
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(GemmParams p) {  // 4-wave tiles: two per CU
     constexpr bool PIPE = STG > 0;
     constexpr int kStages = PIPE ? STG : 1;
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
                  "s"(p.part_table), "s"(p.splitk), "s"(p.steps_per_slice), "s"(p.ws_c), "s"(p.ws_p), "s"(p.tickets), "s"(p.xcd_m));
     int tile, slice = 0;
     {
-        const int S = p.splitk > 1 ? p.splitk : 1;
+        const int S = SPLITK ? p.splitk : 1;
         const int total = p.tiles_m * p.tiles_n * S;
         const int id = blockIdx.x;
         const int q = total >> 3, rem = total & 7;
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
 
     int nk = (Kc + BK - 1) / BK;
     const int kt0 = slice * p.steps_per_slice;  // first K-step of this workgroup (0 unless split-K)
-    if (p.splitk > 1) nk = nk - kt0 < p.steps_per_slice ? nk - kt0 : p.steps_per_slice;
+    if constexpr (SPLITK) nk = nk - kt0 < p.steps_per_slice ? nk - kt0 : p.steps_per_slice;
     int buf = 0;  // ring position: after the loop, the buffer that would be filled next — i.e. a FREE one
     if constexpr (PIPE) {
         // ---- LDS-DMA ring.  Lane (row, physical chunk c') fetches logical chunk c' ^ (row & 7): the DMA
@@ -459,6 +461,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
                 sQ = refill + QOFF;  // nothing left to prefetch: the epilogue's Q tile takes the free buffer
                 issue_q(sQ);
             }
+            // (round 3, measured: the refill's DMA instructions spread BETWEEN this step's MFMAs instead of issued as one burst
+            //  here — same counted waits, same buffers — is slower on every shape: 4096×640×640 12.6 → 14.0 µs, 1024×1280×1280
+            //  equal, and the 128-row tiles spill (address registers stay live across the MFMA stream): 35.7 → 51.6 µs)
             if (!(p.dbg & 2)) compute(smem + buf * STAGE, kt);
             buf = buf + 1 == kStages ? 0 : buf + 1;
         }
@@ -535,8 +540,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
     }
     __syncthreads();
 
-    if constexpr (PIPE && GATE == 0) {
-        if (p.splitk > 1) {
+    if constexpr (SPLITK) {
+        static_assert(PIPE && GATE == 0, "split-K exists on the ungated ring kernels");
+        {
             // In-launch split-K combine (cdna_hip_programming.md, "Projection GEMM" item 2, the sc1 form): every byte that
             // crosses workgroups is stored WRITE-THROUGH (sc1) and loaded sc1 — the XCDs' L2s are not coherent with each
             // other and a CU's L1 is never refreshed, so plain accesses would need an agent-scope release in every slice
@@ -1085,6 +1091,21 @@ int launch_tile(GemmParams p, hipStream_t stream) {
         }
     }
     constexpr int lds = gemm_lds_bytes<BM, BN, T, MAIN, STG, NW, WM>();
+    constexpr bool CAN_SPLIT = MAIN && STG > 0 && NW == 4 && BN == 128 && (BM == 64 || BM == 128);  // what plan_splitk hands out
+    if constexpr (CAN_SPLIT) {
+        if (p.splitk > 1) {  // workspace = [tickets | fp32 tiles | P tiles] (splitk_ws_bytes)
+            auto kern = lora_gemm_kernel<T, BM, BN, MAIN, STG, NW, WM, 0, true>;
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (attr != hipSuccess) return LORA_E_LAUNCH;
+            p.ws_c = reinterpret_cast<float*>(reinterpret_cast<char*>(p.tickets) + kTicketBytes);
+            p.ws_p = p.ws_c + (int64_t)p.tiles_m * p.tiles_n * p.splitk * (BM * BN);
+            LORA_LAUNCH(PK_GEMM_SPLITK, kern, dim3(p.tiles_m * p.tiles_n * p.splitk), dim3(NW * 64), lds, stream, p);
+            LORA_LAUNCH_CHECK();
+            return LORA_OK;
+        }
+    }
+    p.splitk = 0;
     auto kern = lora_gemm_kernel<T, BM, BN, MAIN, STG, NW, WM>;
     if (lds > 48 * 1024) {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1093,13 +1114,7 @@ int launch_tile(GemmParams p, hipStream_t stream) {
     }
     constexpr int prof_id = MAIN ? (BM >= 256 ? PK_GEMM_256x128 : (BM == 128 ? PK_GEMM_128x128 : PK_GEMM_64x64))
                                  : (BM == 128 ? PK_SKINNY_128 : PK_SKINNY_64);
-    const int S = p.splitk > 1 ? p.splitk : 1;
-    const int kind = S > 1 ? (int)PK_GEMM_SPLITK : prof_id;
-    if (S > 1) {  // workspace = [tickets | fp32 tiles | P tiles] (splitk_ws_bytes)
-        p.ws_c = reinterpret_cast<float*>(reinterpret_cast<char*>(p.tickets) + kTicketBytes);
-        p.ws_p = p.ws_c + (int64_t)p.tiles_m * p.tiles_n * S * (BM * BN);
-    }
-    LORA_LAUNCH(kind, kern, dim3(p.tiles_m * p.tiles_n * S), dim3(NW * 64), lds, stream, p);
+    LORA_LAUNCH(prof_id, kern, dim3(p.tiles_m * p.tiles_n), dim3(NW * 64), lds, stream, p);
     LORA_LAUNCH_CHECK();
     return LORA_OK;
 }
