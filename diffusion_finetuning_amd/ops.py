@@ -125,6 +125,7 @@ class _AutoSink:
         self.items = []
         self.armed = False
         self.partials = None
+        self.tables = {}
 
     def defer(self, dy2, x2, t, u, scale, down, up, dtypes):
         self.items.append((dy2, x2, t, u, scale, down, up, dtypes))
@@ -157,7 +158,10 @@ class _AutoSink:
             rows.append([off, r * (N + K), nat.grad_row_blocks(M), 0])
         for dt, probs in by_dtype.items():
             nat.lora_grad_batched(probs, dt, self.device)
-        table = torch.tensor(rows, dtype=torch.int64).to(self.device)
+        key = tuple(map(tuple, rows))
+        table = self.tables.get(key)  # (one host→device copy per distinct set of layer shapes, not one per step)
+        if table is None:
+            table = self.tables[key] = torch.tensor(rows, dtype=torch.int64).to(self.device)
         nat.lora_fold_partials(table, len(rows), max(r_[1] for r_ in rows), part, pstride, grads, False)
         for off, (dy2, x2, t, u, _, down, up, dtypes) in zip(offs, items):
             N, K, r = dy2.shape[1], x2.shape[1], t.shape[1]

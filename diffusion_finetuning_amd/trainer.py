@@ -554,13 +554,15 @@ class LoraTrainer:
 
     # -- one step ---------------------------------------------------------------------------------
     def step(self, latents, noise, timesteps, encoder_hidden_states=None, *, with_prior_preservation=False,
-             prior_loss_weight=1.0, mask=None, seed: Optional[int] = None, input_ids=None):
+             prior_loss_weight=1.0, mask=None, seed: Optional[int] = None, input_ids=None, t_multiplier: float = 1.0):
         """latents fp32 [B,4,h,w] on the device.  Conditioning: `encoder_hidden_states` [B,L,D] — or `input_ids` [B,L]
         (int64), in which case the step itself runs `text_encoder(input_ids)[0]` as the reference's loop does
         (train_lora_dreambooth.py:840); with a LoRA text encoder that is what makes the step recordable.  Noise: either
         pass `noise` (fp32, like latents) and `timesteps` (int64 [B]) — the caller drew them, as the reference does — or
         pass None for both and a `seed`: the step then draws them on the device (Philox keyed by (seed, optimizer step),
-        identical on every rank) inside the prologue kernel.  `mask`: raw [B,1,8h,8w] mask of cli_lora_pti.py:222-247."""
+        identical on every rank) inside the prologue kernel, timesteps uniform on [0, int(1000·t_multiplier)) — the PTI loop's
+        `t_mutliplier` (cli_lora_pti.py:176,190-195).  `mask`: raw [B,1,8h,8w] mask of cli_lora_pti.py:222-247."""
+        self._n_timesteps = max(1, int(self.sqrt_acp.numel() * float(t_multiplier)))
         if (encoder_hidden_states is None) == (input_ids is None):
             raise ValueError("pass exactly one of encoder_hidden_states and input_ids")
         if input_ids is not None and self.text_encoder is None:
@@ -611,7 +613,7 @@ class LoraTrainer:
             if seed is None:
                 raise ValueError("pass noise and timesteps, or a seed for the on-device draw")
             noisy, target, timesteps = nat.ddpm_noise_prologue(latents, self.sqrt_acp, self.sqrt_1macp, self.dtype, seed,
-                                                               self.opt.step_count, self.v_prediction)
+                                                               self.opt.step_count, self.v_prediction, self._n_timesteps)
         else:
             noisy, target = nat.ddpm_add_noise(latents, noise, timesteps, self.sqrt_acp, self.sqrt_1macp, self.dtype,
                                                self.v_prediction)
@@ -641,7 +643,7 @@ class LoraTrainer:
             if seed is None:
                 raise ValueError("pass noise and timesteps, or a seed for the on-device draw")
             noisy, target, t = nat.ddpm_noise_prologue(latents, self.sqrt_acp, self.sqrt_1macp, self.dtype, seed,
-                                                       self.opt.step_count, self.v_prediction)
+                                                       self.opt.step_count, self.v_prediction, self._n_timesteps)
             st["noisy"].copy_(noisy)
             st["target"].copy_(target)
             st["timesteps"].copy_(t)

@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, batch, out):
+def _run(rank, world, port, batch, out, graph=False):
     import itertools
 
     import diffusion_finetuning_amd as dfa
@@ -41,13 +41,16 @@ def _run(rank, world, port, batch, out):
         for i, p in enumerate(plist):
             if i % 2 == 0:
                 p.copy_((torch.randn(p.shape, generator=g) * 0.02).to(dev))
-    trainer = tr.LoraTrainer(unet, lr=1e-3, group_projections=False)  # ungrouped: the bucketed exchange is in play
+    trainer = tr.LoraTrainer(unet, lr=1e-3, group_projections=False, capture_graph=graph)  # ungrouped: the bucketed exchange is in play
     if world > 1:
         assert trainer.exchange.active and trainer.exchange.early_range is not None
+        assert trainer.exchange.single == graph  # a requested recording pins the exchange to ONE all-reduce per step
     for step in range(3):
         latents, noise, ts, ctx = orc.synthetic_batch(step, batch * world, 8, 6, 32)
         sl = slice(rank * batch, (rank + 1) * batch)
         trainer.step(latents[sl].to(dev), noise[sl].to(dev), ts[sl].to(dev), ctx[sl].to(dev))
+    if graph:
+        assert trainer._graph is not None  # the steps really were replays
     state = trainer.slab.params[: trainer.slab.numel].cpu()
     if world > 1:
         gathered = [torch.zeros_like(state) for _ in range(world)]
@@ -71,6 +74,28 @@ def test_two_ranks_equal_one_rank_with_double_batch():
         p.join(timeout=300)
         assert p.exitcode == 0
     single = ctx.Process(target=_run, args=(0, 1, port, 4, q))
+    single.start()
+    one = torch.from_numpy(q.get(timeout=300))
+    single.join(timeout=300)
+    assert single.exitcode == 0
+    err = ((two - one).norm() / one.norm()).item()
+    assert err < 1e-4, err
+
+
+def test_two_ranks_replaying_recorded_steps_equal_one_rank_with_double_batch():
+    """The same equivalence with `capture_graph=True` on both ranks: forward + backward replayed from each rank's hipGraph
+    with a process group of two alive, the slab exchanged in one all-reduce between replay and optimizer."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, 2, port, 2, q, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    two = torch.from_numpy(q.get(timeout=300))
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    single = ctx.Process(target=_run, args=(0, 1, port, 4, q, False))
     single.start()
     one = torch.from_numpy(q.get(timeout=300))
     single.join(timeout=300)

@@ -1393,3 +1393,28 @@ def test_drop_in_backward_defers_factor_gradients_into_one_batched_launch(tiny_u
     assert calls == []  # per-layer launches
     for p, g in zip(plist, deferred):
         assert relerr(p.grad, g) < 1e-5, relerr(p.grad, g)
+
+
+def test_seeded_step_draws_timesteps_below_t_multiplier(tiny_unet_factory, monkeypatch):
+    """cli_lora_pti.py:176,190-195: the PTI loop draws timesteps on [0, int(1000·t_mutliplier)).  The seeded step hands that
+    bound to the prologue kernel — host-launched and recorded steps alike — and the draw respects it."""
+    seen = []
+    real = nat.ddpm_noise_prologue
+
+    def spy(*a, **kw):
+        out = real(*a, **kw)
+        seen.append((a[7] if len(a) > 7 else kw.get("n_timesteps", 1000), int(out[2].max().item())))
+        return out
+
+    monkeypatch.setattr(nat, "ddpm_noise_prologue", spy)
+    for graph in (False, True):
+        unet = tiny_unet_factory(seed=1).to(DEV)
+        dfa.inject_trainable_lora(unet, r=4)
+        trainer = tr.LoraTrainer(unet, lr=1e-3, capture_graph=graph)
+        lat, _, _, ctx = orc.synthetic_batch(0, 4, 8, 6, 32)
+        del seen[:]
+        for _ in range(3):
+            assert torch.isfinite(trainer.step(lat.to(DEV), None, None, ctx.to(DEV), seed=9, t_multiplier=0.05)).all()
+        assert seen and all(n == 50 and tmax < 50 for n, tmax in seen), seen
+        trainer.step(lat.to(DEV), None, None, ctx.to(DEV), seed=9)
+        assert seen[-1][0] == 1000
