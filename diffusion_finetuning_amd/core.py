@@ -132,11 +132,12 @@ def inject_trainable_lora(
     """Wraps every target nn.Linear and returns ([up.parameters(), down.parameters(), ...], names)
     (reference: lora.py:137-183).  `loras` is a path to a positional `[up0, down0, up1, ...]` .pt list; unlike
     the reference (which raises TypeError on its own files) plain tensors are accepted and cast."""
-    params, names = [], []
+    params, names, wrapped_modules = [], [], []
     if loras is not None:
         loras = torch.load(loras, map_location="cpu", weights_only=True)
     for holder, name, child in _find_modules(model, target_replace_module, search_class=[nn.Linear]):
         wrapped = _wrap_linear(holder, name, child, r, follow_weight=False)
+        wrapped_modules.append(wrapped)
         wrapped.to(child.weight.device).to(child.weight.dtype)
         if loras is not None:
             up, down = loras.pop(0), loras.pop(0)
@@ -148,6 +149,9 @@ def inject_trainable_lora(
         wrapped.lora_up.weight.requires_grad = True
         wrapped.lora_down.weight.requires_grad = True
         names.append(name)
+    from .ops import register_pack_group
+
+    register_pack_group(wrapped_modules)  # drop-in mode: one pack launch per parameter update for all of them (ops.PackRegistry)
     return params, names
 
 

@@ -175,6 +175,84 @@ class _AutoSink:
                     p.grad += g
 
 
+class PackRegistry:
+    """Drop-in mode (no trainer.LoraSlab): the packed compute-dtype factors of ALL layers one `inject_trainable_lora` call
+    wrapped, refreshed by ONE `lora_pack_items` launch when a forward finds its own factors changed (an optimizer step, a
+    loaded file, `.to()`) instead of one `lora_pack_factors` launch + two allocations per layer call.  What the reference pays
+    at this point is autocast's per-call cast of `lora_down/lora_up.weight` (lora.py:50 under train_lora_dreambooth.py:489-494)."""
+
+    def __init__(self, modules):
+        self.modules = [m for m in modules if m.lora_down.weight.shape[0] <= 16]
+        self.index = {id(m): i for i, m in enumerate(self.modules)}
+        self.state = None  # (dtype, device, per-module (ptr, version) pairs) the packed buffer was built from
+        self.views = None
+        self.table = None
+        self.ptrs = None
+
+    def _signature(self):
+        return tuple((m.lora_down.weight.data_ptr(), m.lora_down.weight._version, m.lora_up.weight.data_ptr(),
+                      m.lora_up.weight._version) for m in self.modules)
+
+    def get(self, module, cdtype):
+        i = self.index.get(id(module))
+        if i is None:
+            return None
+        d, u = module.lora_down.weight, module.lora_up.weight
+        if d.dtype != torch.float32 or u.dtype != torch.float32 or not d.is_cuda:
+            return None  # (factors held in another dtype are cast per call, as before)
+        st = self.state
+        if st is None or st[0] != cdtype or st[1] != d.device or st[2][i] != (d.data_ptr(), d._version, u.data_ptr(), u._version):
+            if not self._repack(cdtype, d.device):
+                return None
+        return self.views[i]
+
+    def _repack(self, cdtype, device):
+        mods = self.modules
+        if any(m.lora_down.weight.dtype != torch.float32 or m.lora_down.weight.device != device or
+               not m.lora_down.weight.is_contiguous() or not m.lora_up.weight.is_contiguous() for m in mods):
+            return False
+        if torch.cuda.is_current_stream_capturing():
+            return False
+        ptrs = tuple((m.lora_down.weight.data_ptr(), m.lora_up.weight.data_ptr()) for m in mods)
+        if self.table is None or self.ptrs != ptrs or self.views is None or self.views[0][0].dtype != cdtype:
+            # element offsets relative to ONE base pointer: the factors live in separate allocations, the pack kernel adds a
+            # signed 64-bit offset to its `params` argument
+            base = mods[0].lora_down.weight
+            rows, views_at, off = [], [], 0
+            for m in mods:
+                r, K = m.lora_down.weight.shape
+                N = m.lora_up.weight.shape[0]
+                rows.append([(m.lora_down.weight.data_ptr() - base.data_ptr()) // 4, 0, K, r, off, K, off + 16 * K, 16])
+                rows.append([(m.lora_up.weight.data_ptr() - base.data_ptr()) // 4, 1, N, r, off + 32 * K, N,
+                             off + 32 * K + 16 * N, 16])
+                views_at.append((off, K, N))
+                off += 32 * (K + N)
+            self.packed = torch.empty(off, dtype=cdtype, device=device)
+            self.table = torch.tensor(rows, dtype=torch.int64).to(device)
+            self.maxlen = max(r_[2] for r_ in rows)
+            self.views = [(self.packed[o:o + 32 * K], self.packed[o + 32 * K:o + 32 * (K + N)]) for o, K, N in views_at]
+            self.ptrs = ptrs
+            self.base = base
+        nat.lora_pack_items(self.table, self.table.shape[0], self.maxlen, self.base.detach(), self.packed)
+        self.state = (cdtype, device, tuple((m.lora_down.weight.data_ptr(), m.lora_down.weight._version,
+                                             m.lora_up.weight.data_ptr(), m.lora_up.weight._version) for m in mods))
+        return True
+
+
+def register_pack_group(modules) -> None:
+    """Called by `inject_trainable_lora` with the modules it wrapped (core.py)."""
+    import os
+
+    if os.environ.get("DFA_PACK_REGISTRY", "1") == "0":
+        return
+    modules = list(modules)
+    if len(modules) < 2:
+        return
+    reg = PackRegistry(modules)
+    for m in reg.modules:
+        m.__dict__["_dfa_packreg"] = reg
+
+
 _auto_sinks = {}
 
 
@@ -403,6 +481,10 @@ def lora_linear(module, x: torch.Tensor, gate: bool = False) -> torch.Tensor:
     packed = module.__dict__.get("_dfa_packed")
     if packed is not None and packed[0].dtype != cdtype:
         packed = None
+    if packed is None and sink is None:
+        reg = module.__dict__.get("_dfa_packreg")
+        if reg is not None:
+            packed = reg.get(module, cdtype)  # drop-in mode: all layers' packed factors from one launch per update
     fn = _LoraProjGatedFn if gate == "pair" else (_LoraGegluFn if gate else _LoraLinearFn)
     return fn.apply(x, down, up, w, wt, bias, float(module.scale), sink, packed)
 

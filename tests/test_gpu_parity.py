@@ -1378,13 +1378,29 @@ def test_drop_in_backward_defers_factor_gradients_into_one_batched_launch(tiny_u
         pred = unet(lat.to(DEV), ts.to(DEV), ctx.to(DEV)).sample
         dfa.ddpm_mse_loss(pred, noise.to(DEV)).backward()
 
+    packs = {"items": 0, "per_layer": 0}
+    real_items, real_one = nat.lora_pack_items, nat.lora_pack_factors
+    monkeypatch.setattr(nat, "lora_pack_items", lambda *a, **k: (packs.__setitem__("items", packs["items"] + 1), real_items(*a, **k))[1])
+    monkeypatch.setattr(nat, "lora_pack_factors", lambda *a, **k: (packs.__setitem__("per_layer", packs["per_layer"] + 1), real_one(*a, **k))[1])
     backward()
     n_layers = len(plist) // 2
     assert calls == [2 * n_layers]  # every layer's two reductions in one call
+    # ... and the packed compute-dtype factors of all layers come from ONE launch per parameter update (ops.PackRegistry):
+    # none for a second pass over unchanged factors, one again after an optimizer-style in-place update
+    assert packs == {"items": 1, "per_layer": 0}, packs
     deferred = [p.grad.clone() for p in plist]
     backward()  # accumulation into existing .grad
+    assert packs == {"items": 1, "per_layer": 0}, packs
     for p, g in zip(plist, deferred):
         assert relerr(p.grad, 2 * g) < 1e-5
+    with torch.no_grad():
+        plist[0].mul_(1.0)  # an in-place update bumps the version: the next forward repacks (everything, once)
+    for p in plist:
+        p.grad = None
+    backward()
+    assert packs == {"items": 2, "per_layer": 0}, packs
+    for p, g in zip(plist, deferred):
+        assert relerr(p.grad, g) < 1e-5
     for p in plist:
         p.grad = None
     monkeypatch.setenv("DFA_DEFER_GRADS", "0")
