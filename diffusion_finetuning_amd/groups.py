@@ -51,6 +51,16 @@ class _FrozenCat:
             self._wt = nat.lora_cast_matrix(self._w, cdtype, True)
         return self._w, self._wt
 
+    def bias(self, cdtype: torch.dtype):
+        """[b0; b1; ...] in the compute dtype (None when the members have no bias), rebuilt when a member's bias changes."""
+        bs = [l.linear.bias for l in self.layers]
+        if bs[0] is None:
+            return None
+        key = tuple((b.data_ptr(), b._version, b.dtype, b.device) for b in bs) + (cdtype,)
+        if key != getattr(self, "_bkey", None):
+            self._bkey, self._b = key, torch.cat([b.detach().to(cdtype) for b in bs]).contiguous()
+        return self._b
+
 
 _graph_task_id = getattr(torch._C, "_current_graph_task_id", None)
 
@@ -97,9 +107,11 @@ class QKVGroup:
             return False
         lin = layers[0].linear
         r = layers[0].lora_down.weight.shape[0]
+        # (biases: all members or none — the concatenated bias rides on the kernel's own bias argument; CLIP's projections
+        #  carry one, the UNet's q/k/v do not)
         return (len(layers) * r <= RANK_PAD and lin.in_features % 64 == 0 and lin.out_features % 64 == 0 and
                 all(l.linear.in_features == lin.in_features and l.linear.out_features == lin.out_features and
-                    l.linear.bias is None and l.lora_down.weight.shape[0] == r for l in layers))
+                    (l.linear.bias is None) == (lin.bias is None) and l.lora_down.weight.shape[0] == r for l in layers))
 
     def usable(self, x: torch.Tensor, cdtype: torch.dtype) -> bool:
         return (self.Fa is not None and self.Fa.dtype == cdtype and x.is_cuda and _same_scale(self.layers) is not None
@@ -123,7 +135,7 @@ class _QKVProjFn(torch.autograd.Function):
         qkv = torch.empty((M, N3), dtype=cdtype, device=x2.device)
         t = torch.empty((M, rr), dtype=torch.float32, device=x2.device)
         scale = _same_scale(group.layers)
-        nat.lora_gemm_packed(x2, K, w, None, group.Fa, group.Qb, None, None, 0, qkv, t, M, K, N3, rr, scale)
+        nat.lora_gemm_packed(x2, K, w, group.frozen.bias(cdtype), group.Fa, group.Qb, None, None, 0, qkv, t, M, K, N3, rr, scale)
         ctx.save_for_backward(x2, t)
         ctx.group, ctx.wt, ctx.scale = group, wt, scale
         ctx.x_shape, ctx.x_dtype = x.shape, x.dtype
@@ -187,6 +199,41 @@ class _FlashQKVFn(torch.autograd.Function):
         q, out, lse = ctx.saved_tensors
         return nat.attn_flash_bwd_qkv(q, out, dout if dout.is_contiguous() else dout.contiguous(), lse, ctx.heads,
                                       ctx.scale), None, None
+
+
+class _SplitQKVFn(torch.autograd.Function):
+    """[.., 3N] → three [.., N] column-slice VIEWS of it (no copies); backward packs the three incoming gradients into one
+    contiguous [.., 3N] buffer — the dY of `_QKVProjFn` — with one concatenation."""
+
+    @staticmethod
+    def forward(ctx, qkv, n):
+        ctx.n = n
+        return tuple(qkv[..., i * n:(i + 1) * n] for i in range(qkv.shape[-1] // n))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        like = next(g for g in grads if g is not None)
+        return torch.cat([g if g is not None else torch.zeros_like(like) for g in grads], dim=-1), None
+
+
+def shared_projection(group: QKVGroup, member: int, x: torch.Tensor, cdtype: torch.dtype) -> torch.Tensor:
+    """Output of member `member` of a group whose members are called ONE BY ONE by a forward this package does not own —
+    transformers' `CLIPAttention.forward`: `q_proj(h)`, `k_proj(h)`, `v_proj(h)` (LoRA target class "CLIPAttention",
+    lora_diffusion/lora.py:54).  The first member called on a tensor launches the grouped projection and keeps the three
+    column slices; the other members, called on the SAME tensor, take theirs.  The results are views of one [M, 3N] buffer
+    (row stride 3N): what `.view(B, T, heads, d)` and the attention cores accept as they are."""
+    memo = group.__dict__.get("_memo")
+    key = (id(x), x._version, torch.is_grad_enabled())
+    if memo is None or memo[0] != key:
+        factors = [p for l in group.layers for p in (l.lora_down.weight, l.lora_up.weight)]
+        parts = _SplitQKVFn.apply(_QKVProjFn.apply(x, group, cdtype, *factors), group.N)
+        memo = group.__dict__["_memo"] = [key, x, list(parts), 0]  # (x itself is kept: its id cannot be reused meanwhile)
+    out = memo[2][member]
+    memo[3] += 1
+    if memo[3] >= group.G:
+        group.__dict__["_memo"] = None  # every member has taken its slice: drop the references
+    return out
 
 
 def qkv_self_attention(group: QKVGroup, x: torch.Tensor, heads: int, scale: Optional[float], cdtype: torch.dtype):

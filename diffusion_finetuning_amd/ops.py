@@ -475,6 +475,11 @@ def lora_linear(module, x: torch.Tensor, gate: bool = False) -> torch.Tensor:
             "reference trainers do."
         )
     cdtype = _compute_dtype(lin.weight)
+    shared = module.__dict__.get("_dfa_shared")  # (group, member): projections of one input called one by one (CLIP q/k/v)
+    if shared is not None and not gate and shared[0].usable(x, cdtype) and x.dim() >= 2:
+        from .groups import shared_projection
+
+        return shared_projection(shared[0], shared[1], x, cdtype)
     need_wt = torch.is_grad_enabled() and x.requires_grad
     w, wt, bias = _frozen_operands(module, cdtype, need_wt)
     sink = module.__dict__.get("_dfa_grad_sink")

@@ -142,6 +142,18 @@ class LoraSlab:
                     grp = QKVGroup(trio, [self._sinks[index_of[id(l)]] for l in trio])
                     m.__dict__["_dfa_qkv"] = grp
                     self.qkv_groups.append(grp)
+            # transformers' CLIPAttention (LoRA target class of the text encoder, lora.py:54): q_proj / k_proj / v_proj multiply
+            # the same hidden states and are called one after the other by a forward this package does not replace — the
+            # members share one launch through groups.shared_projection (biases ride along; 3·r ≤ 16 rank slots)
+            for name, m in model.named_modules():
+                if m.__class__.__name__ != "CLIPAttention" or not all(hasattr(m, a) for a in ("q_proj", "k_proj", "v_proj")):
+                    continue
+                trio = [m.q_proj, m.k_proj, m.v_proj]
+                if all(id(l) in index_of for l in trio) and QKVGroup.eligible(trio):
+                    grp = QKVGroup(trio, [self._sinks[index_of[id(l)]] for l in trio])
+                    for i, l in enumerate(trio):
+                        l.__dict__["_dfa_shared"] = (grp, i)
+                    self.qkv_groups.append(grp)
             for mods in cross.values():
                 layers = [l for m in mods for l in (m.to_k, m.to_v)]
                 if len(mods) < 2 or not CtxKVGroup.eligible(layers):
@@ -260,6 +272,7 @@ class LoraSlab:
         for layer in self.layers:
             layer.__dict__.pop("_dfa_grad_sink", None)
             layer.__dict__.pop("_dfa_packed", None)
+            layer.__dict__.pop("_dfa_shared", None)
         for model in self.models:
             for m in model.modules():
                 m.__dict__.pop("_dfa_qkv", None)

@@ -574,3 +574,50 @@ def test_full_size_cfg3_unet_plus_clip_l_text_encoder_step_vs_cpu_oracle(relerr)
     assert not trainer.opt.overflowed()
     _check_update(trainer.slab.params[: trainer.slab.numel].cpu(), want, init_state,
                   trainer.slab.grads[: trainer.slab.numel].cpu(), ref_grad, trainer.slab.offsets, relerr, loss, ref_loss.item())
+
+
+def test_clip_attention_projections_share_one_launch(relerr, monkeypatch):
+    """transformers' CLIPAttention calls q_proj / k_proj / v_proj one after the other on the same hidden states (LoRA target
+    class "CLIPAttention", lora.py:54).  Under a trainer the three LoraInjectedLinear members — biases included — run as ONE
+    grouped launch each way (groups.shared_projection), for 3·r ≤ 16 rank slots; the trajectory is the ungrouped one, and at
+    r = 8 (BASELINE config 3) the group does not apply and nothing changes."""
+    from transformers import CLIPTextConfig, CLIPTextModel
+
+    ccfg = CLIPTextConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2, vocab_size=60,
+                          max_position_embeddings=8, bos_token_id=1, eos_token_id=2, pad_token_id=0)
+    g0 = torch.Generator().manual_seed(3)
+    ids = torch.randint(3, 60, (2, 8), generator=g0)
+
+    def train(grouped, r):
+        torch.manual_seed(4)
+        te = CLIPTextModel(ccfg)
+        te.requires_grad_(False)
+        unet = _tiny64(seed=6)
+        unet, te = unet.to(DEV).half(), te.to(DEV).half()
+        gu, _ = dfa.inject_trainable_lora(unet, r=4)
+        gt, _ = dfa.inject_trainable_lora(te, dfa.TEXT_ENCODER_DEFAULT_TARGET_REPLACE, r=r)
+        _warm(list(itertools.chain(*gu)) + list(itertools.chain(*gt)))
+        set_use_memory_efficient_attention_xformers(unet, True)
+        trainer = tr.LoraTrainer(unet, te, lr=1e-3, lr_text=3e-4, group_projections=grouped)
+        calls = []
+        real = nat.lora_gemm_packed
+        monkeypatch.setattr(nat, "lora_gemm_packed", lambda *a, **k: (calls.append((a[11], a[12], a[13])), real(*a, **k))[1])
+        losses = []
+        for step in range(3):
+            lat, noise, ts, _ = orc.synthetic_batch(step, 2, 8, 8, 64)
+            losses.append(trainer.step(lat.to(DEV), noise.to(DEV), ts.to(DEV), input_ids=ids.to(DEV)))
+        monkeypatch.setattr(nat, "lora_gemm_packed", real)
+        # M = 2·8 tokens, 64 ↔ 3·64 (the first layer's input — frozen embeddings — needs no dX: its backward is the P-only form, Nc = 0)
+        clip_calls = [c for c in calls if c[0] == 16 and 192 in (c[1], c[2])]
+        return trainer, trainer.slab.params[: trainer.slab.numel].cpu(), torch.stack(losses).reshape(-1).cpu(), clip_calls
+
+    t_g, got, lg, calls_g = train(True, 4)
+    clip_groups = [g for g in t_g.slab.qkv_groups if g.layers[0].linear.bias is not None]
+    assert len(clip_groups) == 2 and all(g.G == 3 and g.K == 64 and g.N == 64 for g in clip_groups)
+    assert len(calls_g) == 3 * 2 * 2  # 3 steps × 2 CLIP layers × (one forward + one backward-input launch)
+    t_u, want, lu, calls_u = train(False, 4)
+    assert not t_u.slab.qkv_groups and not calls_u
+    assert relerr(lg, lu) < 2e-3 and relerr(got, want) < 2e-3, (relerr(lg, lu), relerr(got, want))
+    t_8, _, l8, calls_8 = train(True, 8)
+    assert not [g for g in t_8.slab.qkv_groups if g.layers[0].linear.bias is not None] and not calls_8  # 3·8 > 16 rank slots
+    assert torch.isfinite(l8).all()
