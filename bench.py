@@ -299,7 +299,7 @@ def _is_lora_kind(name):
     return name.startswith("lora_") or name.startswith("ddpm_")
 
 
-def run_workload(args, cfg_id, rank, world, device, dist, profile=True, want_cpu=False):
+def run_workload(args, cfg_id, rank, world, device, dist, profile=True):
     """Build the workload of BASELINE config `cfg_id`, time args.steps steps of it, optionally run the event pass."""
     from diffusion_finetuning_amd import _native as nat
     from diffusion_finetuning_amd.trainer import LoraTrainer
