@@ -39,3 +39,37 @@ def test_single_rank_runs_in_process():
     assert res.returncode == 0, res.stderr[-2000:]
     assert _json_lines(res.stdout)[0]["n_gpus"] == 1
     assert "launcher:" not in res.stderr
+
+
+def test_bench_workloads_follow_baseline_configs():
+    """bench.CONFIGS mirrors BASELINE.json:configs (index = position in that list; 1 is the CPU case) and the synthetic batches
+    have the shapes each config names: prior preservation doubles the rows (instance then class), config 3 feeds token ids,
+    config 5 is the SD2.1-768 shape; noise and timesteps are rank-invariant, latents / conditioning are sharded."""
+    import json
+
+    import torch
+
+    import bench
+
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert sorted(bench.CONFIGS) == list(range(2, len(base["configs"]) + 1))
+    assert "rank=4" in base["configs"][1] and bench.CONFIGS[2]["rank"] == 4 and bench.CONFIGS[2]["batch"] == 4
+    assert "rank=8" in base["configs"][2] and bench.CONFIGS[3]["rank"] == 8 and bench.CONFIGS[3]["text_encoder"]
+    assert "prior-preservation" in base["configs"][3] and bench.CONFIGS[4]["prior"]
+    assert "rank=16" in base["configs"][4] and bench.CONFIGS[5]["rank"] == 16 and bench.CONFIGS[5]["latent"] == 96
+    c4 = bench.CONFIGS[4]
+    d0 = bench.synthetic_steps(2, c4["batch"], c4["latent"], 0, 2, "cpu", rows_per_image=2)
+    d1 = bench.synthetic_steps(2, c4["batch"], c4["latent"], 1, 2, "cpu", rows_per_image=2)
+    lat, noise, t, ctx = d0[0]
+    assert lat.shape == (8, 4, 64, 64) and noise.shape == lat.shape and t.shape == (8,) and ctx.shape == (8, 77, 768)
+    assert torch.equal(d0[0][1], d1[0][1]) and torch.equal(d0[0][2], d1[0][2])  # noise / timesteps: the same on every rank
+    assert not torch.equal(d0[0][0], d1[0][0]) and not torch.equal(d0[0][3], d1[0][3])  # latents / text: each rank its shard
+    c5 = bench.CONFIGS[5]
+    lat5, _, _, ctx5 = bench.synthetic_steps(1, c5["batch"], c5["latent"], 0, 1, "cpu", c5["ctx_len"], c5["ctx_dim"])[0]
+    assert lat5.shape == (1, 4, 96, 96) and ctx5.shape == (1, 77, 1024)
+    ids = bench.synthetic_steps(1, 4, 64, 0, 1, "cpu", ids=True)[0][3]
+    assert ids.shape == (4, 77) and ids.dtype == torch.int64 and int(ids[:, 0].min()) == 49406 and int(ids[:, -1].max()) == 49407
+    # config 2's tensors are what they were before the other configs existed (the headline's inputs did not move)
+    g = torch.Generator().manual_seed(1000)
+    want = torch.randn(4, 4, 64, 64, generator=g) * 0.18215
+    assert torch.equal(bench.synthetic_steps(1, 4, 64, 0, 1, "cpu")[0][0], want)
