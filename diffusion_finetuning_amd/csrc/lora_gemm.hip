@@ -11,7 +11,7 @@
 // (lora_pack_factors), so it is staged exactly like an operand tile.
 //
 // Structure per workgroup of NW waves (2 row waves × NW/2 column waves; 256 threads in every instantiated form), BM×BN output
-// tile (128×128, 128×160, 64×128, 64×64), 128-byte K-steps:
+// tile (128×128, 128×160, 64×160, 64×128, 64×64), 128-byte K-steps:
 //   - PIPE main loop: an LDS ring of STG = 2–4 stages filled by LDS-DMA (global_load_lds, 16 B per lane, no VGPR staging),
 //     STG−1 K-steps in flight behind a COUNTED s_waitcnt vmcnt and one raw s_barrier per step.  The XOR swizzle of the 16-B
 //     chunks is applied to the per-lane SOURCE address (the DMA writes LDS in lane order) and again on the fragment reads,
@@ -31,8 +31,12 @@
 //   - bias is added in fp32, the tile is transposed through the buffer of the last K-step and stored as whole 16-B row chunks;
 //   - GATE instantiation (the `proj` layer of a GEGLU block): a column tile is 64 hidden columns plus the 64 gate columns behind
 //     them, and the store pass writes h·gelu(g) next to (or instead of) the [h | g] tile — diffusers GEGLU.forward in the epilogue.
+//   - SPLITK instantiations (long contractions on grids too small for the chip): the K-slices of a tile are workgroups of the
+//     SAME launch; each stores its fp32 partials write-through (sc1), draws a ticket, and the last arriver adds the slices in
+//     index order and runs the epilogue above — deterministic, no second launch (plan_splitk()).
 // Workgroups are dealt to XCDs so that the column tiles of one row panel (or the row tiles of one column panel, whichever
-// re-fetches the smaller operand) share an L2.  Tile / ring choice per shape: launch_pipe(), measured with cold weights.
+// re-fetches the smaller operand) share an L2 — or, for square-ish problems, so that each XCD owns a rectangle of the tile grid.
+// Tile / ring / split choice per shape: launch_pipe(), gate_tile_width(), plan_splitk() — all measured with cold weights.
 #include <cstdlib>
 
 #include "common.h"
