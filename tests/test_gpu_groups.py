@@ -588,7 +588,7 @@ def test_clip_attention_projections_share_one_launch(relerr, monkeypatch):
     g0 = torch.Generator().manual_seed(3)
     ids = torch.randint(3, 60, (2, 8), generator=g0)
 
-    def train(grouped, r):
+    def train(grouped, r, graph=False):
         torch.manual_seed(4)
         te = CLIPTextModel(ccfg)
         te.requires_grad_(False)
@@ -598,7 +598,7 @@ def test_clip_attention_projections_share_one_launch(relerr, monkeypatch):
         gt, _ = dfa.inject_trainable_lora(te, dfa.TEXT_ENCODER_DEFAULT_TARGET_REPLACE, r=r)
         _warm(list(itertools.chain(*gu)) + list(itertools.chain(*gt)))
         set_use_memory_efficient_attention_xformers(unet, True)
-        trainer = tr.LoraTrainer(unet, te, lr=1e-3, lr_text=3e-4, group_projections=grouped)
+        trainer = tr.LoraTrainer(unet, te, lr=1e-3, lr_text=3e-4, group_projections=grouped, capture_graph=graph)
         calls = []
         real = nat.lora_gemm_packed
         monkeypatch.setattr(nat, "lora_gemm_packed", lambda *a, **k: (calls.append((a[11], a[12], a[13])), real(*a, **k))[1])
@@ -618,6 +618,10 @@ def test_clip_attention_projections_share_one_launch(relerr, monkeypatch):
     t_u, want, lu, calls_u = train(False, 4)
     assert not t_u.slab.qkv_groups and not calls_u
     assert relerr(lg, lu) < 2e-3 and relerr(got, want) < 2e-3, (relerr(lg, lu), relerr(got, want))
+    # the same grouped step recorded into a hipGraph and replayed (the members' memo lives only inside one forward pass)
+    t_r, got_r, lr_, _ = train(True, 4, graph=True)
+    assert t_r._graph is not None
+    assert relerr(lr_, lg) < 2e-3 and relerr(got_r, got) < 2e-3, (relerr(lr_, lg), relerr(got_r, got))
     t_8, _, l8, calls_8 = train(True, 8)
     assert not [g for g in t_8.slab.qkv_groups if g.layers[0].linear.bias is not None] and not calls_8  # 3·8 > 16 rank slots
     assert torch.isfinite(l8).all()
