@@ -663,10 +663,23 @@ def main():
                 extras.append(e)
             result["extra_configs"] = extras
             try:
-                result["extra"] = {"drop_in": drop_in_route(args, device)}
+                # a fresh process, like a trainer's own: after four workloads in this one the host-bound route measures
+                # 10-15 % low (allocator and interpreter state of the previous models)
+                import subprocess
+
+                torch.cuda.empty_cache()
+                cmd = [sys.executable, os.path.abspath(__file__), "--drop-in", "--steps", str(args.steps), "--warmup", str(args.warmup)]
+                out = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, timeout=600)
+                line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+                d = json.loads(line)
+                result["extra"] = {"drop_in": {"images_s": d["value"], "ms_per_step": d["ms_per_step"], "final_loss": d["final_loss"],
+                                               "route": d["route"], "measured_in": "a fresh child process (bench.py --drop-in)"}}
             except Exception as exc:
-                log(f"drop-in route failed: {exc!r}")
-                result["extra"] = {"drop_in": {"error": repr(exc)}}
+                log(f"drop-in route in a child process failed ({exc!r}); measuring it in this process")
+                try:
+                    result["extra"] = {"drop_in": drop_in_route(args, device)}
+                except Exception as exc2:
+                    result["extra"] = {"drop_in": {"error": repr(exc2)}}
         if world == 1 and not args.no_cpu_baseline:
             torch.cuda.empty_cache()
             result["cpu_baseline"] = cpu_baseline(CONFIGS[2]["rank"], CONFIGS[2]["latent"], args.cpu_steps)
