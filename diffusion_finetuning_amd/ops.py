@@ -167,6 +167,8 @@ class _AutoSink:
             N, K, r = dy2.shape[1], x2.shape[1], t.shape[1]
             for p, g, dt in ((up, grads[off:off + N * r].view(N, r), dtypes[1]),
                              (down, grads[off + N * r:off + r * (N + K)].view(r, K), dtypes[0])):
+                if not p.requires_grad:
+                    continue  # (a factor frozen by the caller: autograd would not have produced its gradient either)
                 if dt != torch.float32:
                     g = g.to(dt)
                 if p.grad is None:
