@@ -13,7 +13,7 @@ _LIB_PATH = os.environ.get("DFA_LIB_PATH") or os.path.join(os.path.dirname(os.pa
 _lib = None
 _lock = threading.Lock()
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 PROF_KINDS = 17
 
 _DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
@@ -61,6 +61,7 @@ SIGNATURES = {
     "lora_fold_partials": (_i32, [_vp, _i32, _i64, _vp, _i64, _vp, _i32, _vp]),
     "lora_gemm_packed": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _f32,
                                 _i64, _vp, _i64, _i32, _vp]),
+    "lora_gemm_parts": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "lora_gemm_workspace_bytes": (_i64, [_i64, _i32, _i32, _i32]),
     "lora_linear_bwd_input_ws": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp,
                                         _i64, _vp]),
@@ -370,6 +371,20 @@ def lora_gemm_packed(am, lda: int, bm, bias, fp, qp, tile_part, part_table, n_pa
                                   _ptr(part_table), int(n_parts), _ptr(c), _ptr(p_out), int(M), int(Kc), int(Nc), int(r),
                                   float(scale), int(work_cols), _ptr(ws), 0 if ws is None else ws.numel() * 4,
                                   dtype_code(am.dtype), _stream(am)), "lora_gemm_packed")
+
+
+def lora_gemm_parts(am, bm, bias, fp, qp, c, p_out, ldp: int, M: int, Kc: int, Nc: int, r: int, n_parts: int,
+                    parts_on_k: bool, scale: float) -> bool:
+    """n_parts equal LoRA layers that share an input in one launch at any rank <= 16 (include/lora_hip.h: lora_gemm_parts);
+    False when the library has no kernel for the shape / dtype (the caller runs the layers one by one)."""
+    _require_device(am, bm, bias, fp, qp, c, p_out)
+    st = lib().lora_gemm_parts(_ptr(am), _ptr(bm), _ptr(bias), _ptr(fp), _ptr(qp), _ptr(c), _ptr(p_out), int(ldp), int(M),
+                               int(Kc), int(Nc), int(r), int(n_parts), int(bool(parts_on_k)), float(scale),
+                               dtype_code(am.dtype), _stream(am))
+    if st == -5:
+        return False
+    _check(st, "lora_gemm_parts")
+    return True
 
 
 def lora_reduce_partials(partials, part_stride: int, n_blocks: int, grads, n: int, accumulate: bool) -> None:

@@ -67,12 +67,22 @@ struct GemmParams {
     //         into P} — blockIdx covers (row tile, part), every part contracts its own column range of Am.
     const int* tile_part;
     const int64_t* part_table;
+    // Equal-width parts without a table (grouped q/k/v at any rank <= 16: lora_gemm_parts):
+    //  n_parts > 0, parts_on_k == 0 (forward):  the Nc output columns are n_parts runs of part_n; a column tile lies inside one
+    //         part (the host picks BN | part_n), multiplies with that part's factor rows Fp + part·16·Kc, and the part's first
+    //         tile writes its P columns [part·r, part·r + r) of the [M, ldp] buffer;
+    //  n_parts > 0, parts_on_k == 1 (backward-input, KP kernels): the CONTRACTION is n_parts runs of part_n — Fp [16, Kc]
+    //         holds part g's factor rows in its own column run, P_g = Am[:, run g]·F_gᵀ accumulates per part, and the
+    //         epilogue adds s·Σ_g P_g·Q_gᵀ with Qp = [n_parts][Nc, 16].
+    int n_parts, part_n, parts_on_k;
+    int ldp;  // row stride of P in floats (r for a single layer)
     // Split-K (contractions on grids too small for the chip): slice s of a tile contracts K-steps [s·steps_per_slice, …),
     // STORES its fp32 accumulators at ws_c[tile][s] (BM·BN floats in the lanes' own register order) and its partial P at
     // ws_p[tile][s][BM][16], and takes a ticket of the tile.  The workgroup that draws the LAST ticket adds the slices
     // 0..S-1 in index order — whoever arrives last, the sum has one order: deterministic — and runs the normal epilogue
     // (rank-r term, bias, store) on the totals; it leaves the ticket at zero for the next launch.  splitk <= 1: off.
     int splitk, steps_per_slice;
+    int split_aff;      // 1: slice s of every tile runs on XCD s % S (S divides 8) — a byte of Am / Bm is fetched by ONE L2
     float* ws_c;
     float* ws_p;
     unsigned* tickets;  // one per output tile, zero on entry, zero again on exit
@@ -148,7 +158,8 @@ template <int BM, int BN, typename T, bool MAIN, int STG, int NW, int WM> conste
 // NW waves as WM row waves × NW/WM column waves; every wave owns a (BM/WM) × (BN·WM/NW) piece of the tile.
 // SPLITK: the launch cuts its contraction into K-slices (in-launch combine, below) — instantiations of their own, so that the
 // unsplit kernels carry none of that code and profilers can tell the two apart by name
-template <typename T, int BM, int BN, bool MAIN, int STG, int NW, int WM, int GATE = 0, bool SPLITK = false>  // GATE: 0 none, 1 GEGLU forward, 2 GEGLU backward
+// KP > 1: the contraction consists of KP equal parts with a factor pair each (grouped q/k/v backward-input at 3r > 16)
+template <typename T, int BM, int BN, bool MAIN, int STG, int NW, int WM, int GATE = 0, bool SPLITK = false, int KP = 1>  // GATE: 0 none, 1 GEGLU forward, 2 GEGLU backward
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(GemmParams p) {  // 4-wave tiles: two per CU
     constexpr bool PIPE = STG > 0;
     constexpr int kStages = PIPE ? STG : 1;
@@ -193,7 +204,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
     // Pull every kernel argument into SGPRs now: one scalar-load round trip instead of two dependent ones.
     asm volatile("" ::"s"(p.Am), "s"(p.Bm), "s"(p.bias), "s"(p.Fp), "s"(p.Qp), "s"(p.C), "s"(p.P), "s"(p.M), "s"(p.Kc),
                  "s"(p.Nc), "s"(p.scale), "s"(p.tiles_m), "s"(p.tiles_n), "s"(p.col_major), "s"(p.lda), "s"(p.tile_part),
-                 "s"(p.part_table), "s"(p.splitk), "s"(p.steps_per_slice), "s"(p.ws_c), "s"(p.ws_p), "s"(p.tickets), "s"(p.xcd_m));
+                 "s"(p.part_table), "s"(p.splitk), "s"(p.steps_per_slice), "s"(p.ws_c), "s"(p.ws_p), "s"(p.tickets), "s"(p.xcd_m),
+                 "s"(p.split_aff));
     int tile, slice = 0;
     {
         const int S = SPLITK ? p.splitk : 1;
@@ -202,7 +214,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
         const int q = total >> 3, rem = total & 7;
         const int xcd = id & 7, slot = id >> 3;
         tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
-        if (S > 1) {  // the slices of one tile are neighbours: they read the same operand rows, a K-range each
+        if (SPLITK && p.split_aff) {
+            // Slice → XCD affinity (S divides 8): XCD x runs slice x % S of the tiles of sub-range g = x / S (8/S sub-ranges of
+            // the tile list).  A K-range of Am and Bm is then streamed by 8/S L2s instead of by all eight — with S = 8 every
+            // operand byte is fetched by exactly one XCD (round 3's run order made every XCD stream ALL of Bm: 3.5x the
+            // algorithmic bytes).  The block counts match the round-robin dispatch: XCD x holds total/8 (+1 if x < total % 8)
+            // blocks and total % 8 = S·(tiles % G), so exactly the XCDs of the sub-ranges g < tiles % G take one more tile.
+            const int G = 8 / S, tiles = p.tiles_m * p.tiles_n;
+            const int g = xcd / S, tq = tiles / G, tr = tiles % G;
+            slice = xcd % S;
+            tile = g * tq + (g < tr ? g : tr) + slot;
+        } else if (S > 1) {  // the slices of one tile are neighbours: they read the same operand rows, a K-range each
             slice = tile % S;
             tile = tile / S;
         }
@@ -250,6 +272,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
             Fg += (int64_t)part * kRP * Kc;
             if (Pout != nullptr) Pout += (int64_t)part * p.M * p.r;
             write_p = p.P != nullptr && (e >> 16) != 0;
+        } else if (KP == 1 && p.n_parts > 0) {  // equal parts over the output columns (lora_gemm_parts, forward form)
+            const int part = n0 / p.part_n;
+            Fg += (int64_t)part * kRP * Kc;
+            if (Pout != nullptr) Pout += part * p.r;
+            write_p = p.P != nullptr && n0 == part * p.part_n;
         }
     } else {
         if (p.part_table != nullptr) {
@@ -288,8 +315,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
     // costs no LDS of its own — which is what lets two 128×160 workgroups share a CU — and stays off the prologue.
     constexpr int CPRQ = kRP * (int)sizeof(T) / 16;  // chunks per packed row (2 for 16-bit, 4 for f32)
     constexpr int QOFF = WN * BM * kSPS * 4;         // behind the P image when both land in the same buffer
-    auto issue_q = [&](char* dst) {
-        const T* Qg = static_cast<const T*>(p.Qp);
+    auto issue_q = [&](char* dst, int part = 0) {
+        const T* Qg = static_cast<const T*>(p.Qp) + (int64_t)part * p.Nc * kRP;
         for (int base = wave * 64; base < BN * CPRQ; base += NT) {
             const int idx = base + lane;
             const int n = idx / CPRQ, ch = idx - n * CPRQ;
@@ -327,12 +354,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
 
     f32x4 acc[MAIN ? MI : 1][MAIN ? NI : 1];
     f32x4 pacc[MI];
+    f32x4 pacc_x[KP > 1 ? KP - 1 : 1][MI];  // KP kernels: parts 1.. (part 0 uses pacc)
 #pragma unroll
     for (int i = 0; i < (MAIN ? MI : 1); ++i)
 #pragma unroll
         for (int j = 0; j < (MAIN ? NI : 1); ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < MI; ++i) pacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < (KP > 1 ? KP - 1 : 1); ++g)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) pacc_x[g][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int steps_per_part = KP > 1 ? p.part_n / BK : 1;  // (part_n % BK == 0: checked on the host)
 
     // ---- one K-step of MFMA work out of a staged buffer ------------------------------------
     auto compute = [&](const char* st, int kt) {
@@ -354,8 +387,22 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
                     af[mi] = *reinterpret_cast<const Frag*>(sA + lds_off(wm * WTM + mi * 16 + l15, chunk));
                 if ((kt * 2 + ks) % WN == wn) {
                     const Frag ff = *reinterpret_cast<const Frag*>(sF + lds_off(l15, chunk));
+                    if constexpr (KP > 1) {
+                        const int part = kt / steps_per_part;  // wave-uniform: the K-step lies inside one part's column run
+                        if (part == 0) {
+#pragma unroll
+                            for (int mi = 0; mi < MI; ++mi) pacc[mi] = Mfma<T>::run(ff, af[mi], pacc[mi]);
+                        }
+#pragma unroll
+                        for (int g = 1; g < KP; ++g)
+                            if (part == g) {
+#pragma unroll
+                                for (int mi = 0; mi < MI; ++mi) pacc_x[g - 1][mi] = Mfma<T>::run(ff, af[mi], pacc_x[g - 1][mi]);
+                            }
+                    } else {
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) pacc[mi] = Mfma<T>::run(ff, af[mi], pacc[mi]);
+                    }
                 }
                 if constexpr (MAIN) {
                     Frag bf[NI];
@@ -647,11 +694,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
     constexpr bool PACKED_P = MAIN && !F32 && PIPE;  // the rank-r term's operand is built ONCE per row, cooperatively
     constexpr int kPkStride = 80;                     // bytes per row of the packed image [hi j0..15 | lo j0..15] (+16 pad)
     char* const sPk = reinterpret_cast<char*>(sP) + QOFF + (MAIN ? BN * kRP * (int)sizeof(T) : 0);
-    if constexpr (PACKED_P) {
-        // thread = (row, half of the 16 rank slots): sums the wave partials, writes P out, and leaves s·P split into a
-        // high and a low 16-bit part in MFMA operand order — every wave then fetches a fragment with ONE 16-byte read
-        // instead of rebuilding it from 2·WN fp32 reads and 40 conversions per lane (4× redundantly across the workgroup)
-        static_assert(QOFF + BN * kRP * (int)sizeof(T) + BM * kPkStride <= STAGE, "P partials + Q tile + packed P fit one buffer");
+    static_assert(KP == 1 || (PACKED_P && !SPLITK && GATE == 0), "part-wise contractions exist on the plain 16-bit ring kernels");
+    // thread = (row, half of the 16 rank slots): sums the wave partials, writes P out, and leaves s·P split into a
+    // high and a low 16-bit part in MFMA operand order — every wave then fetches a fragment with ONE 16-byte read
+    // instead of rebuilding it from 2·WN fp32 reads and 40 conversions per lane (4× redundantly across the workgroup)
+    auto build_packed = [&](int part) {
+        if constexpr (PACKED_P) {
+        static_assert(!PACKED_P || QOFF + BN * kRP * (int)sizeof(T) + BM * kPkStride <= STAGE, "P partials + Q tile + packed P fit one buffer");
         const int half = tid & 1;
         for (int row = tid >> 1; row < BM; row += NT / 2) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
@@ -665,7 +714,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
             if (write_p && m0 + row < p.M) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    if (half * 8 + e < p.r) Pout[(m0 + row) * p.r + half * 8 + e] = v[e];
+                    if (half * 8 + e < p.r) Pout[(m0 + row) * p.ldp + part * p.r + half * 8 + e] = v[e];
             }
             Chunk<T> hi, lo;
 #pragma unroll
@@ -678,6 +727,54 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
             *reinterpret_cast<Chunk<T>*>(sPk + row * kPkStride + 32 + half * 16) = lo;
         }
         __syncthreads();
+        }
+    };
+    // acc += s·P·Qᵀ as ONE extra MFMA K-step out of the packed record and the Q tile at `q_base`
+    auto rank_step_packed = [&](const char* q_base) {
+        if constexpr (PACKED_P) {
+            using Frag = typename Mfma<T>::Frag;
+            const int j0 = 8 * (lq & 1);
+            Frag qf[NI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                qf[ni] = *reinterpret_cast<const Frag*>(q_base + ((wn * WTN + ni * 16 + l15) * kRP + j0) * (int)sizeof(T));
+            Frag pf[MI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                pf[mi] = *reinterpret_cast<const Frag*>(sPk + (wm * WTM + mi * 16 + l15) * kPkStride + lq * 16);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = Mfma<T>::run(qf[ni], pf[mi], acc[mi][ni]);
+        }
+    };
+    if constexpr (PACKED_P) {
+        if constexpr (KP > 1) {
+            // Parts 1.. of the epilogue factor go into the buffer of the last K-step (free since the barrier behind the P
+            // exchange; the C tile lands there only after the last part): fetched by DMA while part 0 is worked on.
+            constexpr int QB = BN * kRP * (int)sizeof(T);
+            static_assert((KP - 1) * QB <= STAGE, "the epilogue factors of parts 1.. fit the last step's buffer");
+#pragma unroll
+            for (int g = 1; g < KP; ++g) issue_q(last_buf + (g - 1) * QB, g);
+            build_packed(0);
+            rank_step_packed(sQ);
+#pragma unroll
+            for (int g = 1; g < KP; ++g) {
+                __syncthreads();  // every wave is done with the previous part's partials and packed record
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int row = wm * WTM + mi * 16 + l15;
+                    *reinterpret_cast<f32x4*>(&sP[(wn * BM + row) * kSPS + lq * 4]) = pacc_x[g - 1][mi];
+                }
+                if (g == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of Q_1.. has landed
+                __syncthreads();
+                build_packed(g);
+                rank_step_packed(last_buf + (g - 1) * QB);
+            }
+            __syncthreads();  // the Q tiles in the last step's buffer are dead: the C tile may land there
+        } else {
+            build_packed(0);
+        }
     } else if (write_p) {
         const int half = tid & 1;
         for (int row = tid >> 1; row < BM && m0 + row < p.M; row += NT / 2) {
@@ -688,7 +785,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
                     float v = 0.f;
 #pragma unroll
                     for (int w = 0; w < WN; ++w) v += sP[(w * BM + row) * kSPS + j];
-                    Pout[(m0 + row) * p.r + j] = v;
+                    Pout[(m0 + row) * p.ldp + j] = v;
                 }
             }
         }
@@ -699,22 +796,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
         // ---- epilogue 2: acc += s·P·Qᵀ as one extra MFMA K-step ---------------------------
         if constexpr (!F32) {
             using Frag = typename Mfma<T>::Frag;
+            if constexpr (PACKED_P) {
+                if constexpr (KP == 1) rank_step_packed(sQ);
+            } else {
             const int j0 = 8 * (lq & 1);
             Frag qf[NI];
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
                 qf[ni] = *reinterpret_cast<const Frag*>(
                     sQ + ((wn * WTN + ni * 16 + l15) * kRP + j0) * (int)sizeof(T));
-            if constexpr (PACKED_P) {
-                Frag pf[MI];
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-                    pf[mi] = *reinterpret_cast<const Frag*>(sPk + (wm * WTM + mi * 16 + l15) * kPkStride + lq * 16);
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = Mfma<T>::run(qf[ni], pf[mi], acc[mi][ni]);
-            } else {
             constexpr int MG = MI < 4 ? MI : 4;  // row fragments whose P image is fetched together
 #pragma unroll
             for (int mg = 0; mg < MI; mg += MG) {
@@ -1019,6 +1109,15 @@ __global__ __launch_bounds__(256) void pack_factors_batched_kernel(const int64_t
 struct SplitPlan {
     int S, bm;
 };
+// Slice → XCD affinity (LORA_SPLIT_AFFINITY=1; off by default).  Measured in round 4 (profiles/r04_splitk_xcd_affinity_ab.log,
+// weights cold): it cuts the operand fetch to |Am| + |Bm| as intended, but the S slices of a tile then sit on S different XCDs,
+// so the last arriver's slab reads cross the fabric instead of hitting the L2 that holds the neighbours' write-through
+// stores — 4096×5120→640 49.5 → 64.0 µs, 1024×10240→1280 57.7 → 71.4, 256×10240→1280 29.8 → 35.1, grouped q/k/v backward at
+// 1024 rows 30.6 → 39.7: these launches are paced by the combine and their fixed phases, not by operand traffic.
+bool split_affinity() {
+    static const int env = [] { const char* e = getenv("LORA_SPLIT_AFFINITY"); return e ? atoi(e) : 0; }();
+    return env != 0;
+}
 constexpr int kTicketBytes = LORA_GEMM_WS_TICKET_BYTES;  // ticket header of the workspace: one u32 per output tile
 SplitPlan plan_splitk(int64_t M, int Kc, int Nc, int esize) {
     static const int env = [] { const char* e = getenv("LORA_SPLITK"); return e ? atoi(e) : -1; }();
@@ -1041,6 +1140,12 @@ SplitPlan plan_splitk(int64_t M, int Kc, int Nc, int esize) {
     while (S > 1 && nk / S < min_steps) --S;
     if (env > 1) S = env > 8 ? 8 : env;
     while (S > 1 && (S - 1) * ((nk + S - 1) / S) >= nk) --S;  // every slice owns at least one K-step
+    if (split_affinity() && env <= 1) {
+        // slice → XCD affinity needs S | 8: the nearest power of two that still leaves min_steps per slice (3 → 4, 6 → 8 / 4)
+        int S2 = S >= 6 ? 8 : (S >= 3 ? 4 : S);
+        while (S2 > 1 && nk / S2 < min_steps) S2 >>= 1;
+        S = S2;
+    }
     return SplitPlan{S, bm};
 }
 int64_t splitk_ws_bytes(int64_t M, int Nc, const SplitPlan& sp) {
@@ -1074,10 +1179,11 @@ template <typename T, int BM, int BN, bool MAIN, int STG, int NW = 4, int WM = 2
 int launch_tile(GemmParams p, hipStream_t stream) {
     p.tiles_m = (int)((p.M + BM - 1) / BM);
     p.tiles_n = MAIN ? (p.Nc + BN - 1) / BN : (p.part_table ? p.tiles_n : 1);  // skinny grouped: tiles_n = parts
+    if (p.ldp == 0) p.ldp = p.r;
     static const int order_env = [] { const char* e = getenv("LORA_FORCE_COLMAJOR"); return e ? atoi(e) : -1; }();
     p.col_major = order_env >= 0 ? order_env : (MAIN && (int64_t)p.Nc > p.M ? 1 : 0);
     p.xcd_m = 1;
-    if (MAIN && p.splitk <= 1 && p.tile_part == nullptr) {
+    if (MAIN && p.splitk <= 1 && p.tile_part == nullptr && p.n_parts == 0) {
         // Which XCD grid re-fetches the fewest operand bytes?  An xm × xn grid (xm·xn = 8) makes the eight L2s fetch
         // xn·|Am| + xm·|Bm| in total; (8,1) and (1,8) are the row- / column-major runs above (any tile counts), the 2-D
         // grids need exact splits.  Only square-ish problems (the 1280-wide layers at 1024 / 256 rows) pick one.
@@ -1102,6 +1208,7 @@ int launch_tile(GemmParams p, hipStream_t stream) {
             static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (attr != hipSuccess) return LORA_E_LAUNCH;
+            p.split_aff = split_affinity() && (8 % p.splitk) == 0 ? 1 : 0;
             p.ws_c = reinterpret_cast<float*>(reinterpret_cast<char*>(p.tickets) + kTicketBytes);
             p.ws_p = p.ws_c + (int64_t)p.tiles_m * p.tiles_n * p.splitk * (BM * BN);
             LORA_LAUNCH(PK_GEMM_SPLITK, kern, dim3(p.tiles_m * p.tiles_n * p.splitk), dim3(NW * 64), lds, stream, p);
@@ -1146,6 +1253,7 @@ int launch_gate_bn(GemmParams p, hipStream_t stream) {
     constexpr int BM = 128;
     p.tiles_m = (int)((p.M + BM - 1) / BM);
     p.tiles_n = p.gateF / (BN / 2);
+    p.ldp = p.r;
     p.col_major = (int64_t)p.Nc > p.M ? 1 : 0;
     constexpr int lds = gemm_lds_bytes<BM, BN, T, true, 2, 4, 2>();
     auto kern = lora_gemm_kernel<T, BM, BN, true, 2, 4, 2, 1>;
@@ -1169,6 +1277,7 @@ int launch_gate_bwd_bn(GemmParams p, hipStream_t stream) {
     constexpr int BM = 128;
     p.tiles_m = (int)((p.M + BM - 1) / BM);
     p.tiles_n = p.Nc / BN;
+    p.ldp = p.r;
     p.col_major = (int64_t)p.Nc > p.M ? 1 : 0;
     constexpr int lds = gemm_lds_bytes<BM, BN, T, true, 2, 4, 2>();
     auto kern = lora_gemm_kernel<T, BM, BN, true, 2, 4, 2, 2>;
@@ -1183,6 +1292,39 @@ template <typename T>
 int launch_gate_bwd(GemmParams p, hipStream_t stream) {
     if (gate_tile_width((p.M + 127) / 128, p.Nc, true) == 160) return launch_gate_bwd_bn<T, 160>(p, stream);
     return launch_gate_bwd_bn<T, 128>(p, stream);
+}
+
+// Backward-input of a grouped projection whose contraction consists of KP equal parts (lora_gemm_parts, parts_on_k): the
+// part-wise kernels exist on 64-row tiles — 64×160 where the output width wants it (320, 960), else 64×128, else 64×64.
+template <typename T, int BM, int BN, int STG, int KP>
+int launch_kparts_tile(GemmParams p, hipStream_t stream) {
+    p.tiles_m = (int)((p.M + BM - 1) / BM);
+    p.tiles_n = (p.Nc + BN - 1) / BN;
+    p.col_major = (int64_t)p.Nc > p.M ? 1 : 0;
+    p.xcd_m = 1;
+    p.splitk = 0;
+    constexpr int lds = gemm_lds_bytes<BM, BN, T, true, STG, 4, 2>();
+    auto kern = lora_gemm_kernel<T, BM, BN, true, STG, 4, 2, 0, false, KP>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (attr != hipSuccess) return LORA_E_LAUNCH;
+    LORA_LAUNCH(PK_GEMM_64x64, kern, dim3(p.tiles_m * p.tiles_n), dim3(256), lds, stream, p);
+    LORA_LAUNCH_CHECK();
+    return LORA_OK;
+}
+template <typename T, int KP>
+int launch_kparts(const GemmParams& p, hipStream_t stream) {
+    if constexpr (sizeof(T) == 2) {
+        const int64_t tm = (p.M + 63) / 64;
+        if ((p.Nc % 160) == 0 && (p.Nc % 128) != 0) return launch_kparts_tile<T, 64, 160, 2, KP>(p, stream);
+        if ((p.Nc % 128) == 0) {
+            if (tm * (p.Nc / 128) >= 256) return launch_kparts_tile<T, 64, 128, 2, KP>(p, stream);
+            return launch_kparts_tile<T, 64, 128, 3, KP>(p, stream);
+        }
+        return launch_kparts_tile<T, 64, 64, 3, KP>(p, stream);
+    } else {
+        return LORA_E_UNSUPPORTED;
+    }
 }
 
 int forced_tile() {  // tuning knob for tools/gemm_bench.py only
@@ -1223,7 +1365,9 @@ int launch_pipe(const GemmParams& p_in, hipStream_t stream) {
     const int64_t tiles128 = ((p.M + 127) / 128) * ((p.Nc + 127) / 128);
     const int64_t tiles64 = ((p.M + 63) / 64) * ((p.Nc + 63) / 64);
     const int padded = (p.Nc + 127) / 128 * 128;
-    bool big = tiles128 >= 128 && (padded - p.Nc) * 4 <= p.Nc;
+    // equal parts over the output columns: a column tile must lie inside one part
+    const bool p128 = p.n_parts == 0 || (p.part_n % 128) == 0, p160 = p.n_parts == 0 || (p.part_n % 160) == 0;
+    bool big = tiles128 >= 128 && (padded - p.Nc) * 4 <= p.Nc && p128;
     bool deep = tiles64 < 512;
     if (forced_tile() == 0) big = true;
     if (forced_tile() == 2) big = false;
@@ -1235,7 +1379,7 @@ int launch_pipe(const GemmParams& p_in, hipStream_t stream) {
         // level): 128×160 tiles waste no MFMA, LDS or L2→LDS traffic on padding columns (128-wide tiles pad 320 to 384)
         // and re-read the X panel twice instead of three times; two workgroups still share a CU (77.8 KB each)
         const int64_t tiles160 = ((p.M + 127) / 128) * (p.Nc / 160);
-        bool w160 = (p.Nc % 160) == 0 && (p.Nc % 128) != 0 && tiles160 >= 128;
+        bool w160 = (p.Nc % 160) == 0 && ((p.Nc % 128) != 0 || !p128) && tiles160 >= 128 && p160;
         if (forced_tile() == 7) w160 = (p.Nc % 160) == 0;
         if (forced_tile() == 0 || forced_tile() == 2 || forced_tile() == 1) w160 = false;  // 1: the 128|64-square rules only
         // ... and when that grid has fewer than 384 tiles (the 320-wide projections at 16384 rows: 256 tiles, one per CU),
@@ -1259,12 +1403,12 @@ int launch_pipe(const GemmParams& p_in, hipStream_t stream) {
         //  is SLOWER, 15.4 → 16.0 → 16.3 µs: a lone workgroup is not waiting on prefetch depth)
         // (also measured on this grid, round 3: the same tile as ONE 8-wave workgroup — 4×2 waves, two per SIMD instead of
         //  one — 15.1 vs 15.2 µs behind 3 stages, 19.2 behind 2: neither the wave count nor a ring deeper than 3 moves it)
-        if (!big && tiles128 >= 64 && (p.Nc % 128) == 0 && stg_env == 0 && forced_tile() < 0)
+        if (!big && tiles128 >= 64 && (p.Nc % 128) == 0 && p128 && stg_env == 0 && forced_tile() < 0)
             return launch_tile<T, 64, 128, true, 3, 4>(p, stream);
     }
     if constexpr (sizeof(T) == 2) {
         // chip-filling grids whose width divides by 128 AND 160: the tile whose grid wastes less of its last round
-        if (big && tiles128 >= 256 && forced_tile() < 0 && stg_env == 0 && gate_tile_width((p.M + 127) / 128, p.Nc, false) == 160)
+        if (big && p160 && tiles128 >= 256 && forced_tile() < 0 && stg_env == 0 && gate_tile_width((p.M + 127) / 128, p.Nc, false) == 160)
             return launch_tile<T, 128, 160, true, 2, 4>(p, stream);
     }
     if (big) {
@@ -1607,4 +1751,31 @@ extern "C" int lora_gemm_packed(const void* Am, int64_t lda, const void* Bm, con
                             : e * (double)M * kc + e * r * kc,
                   main_part ? 2.0 * M * (double)Kc * Nc + 2.0 * M * r * (double)(Kc + Nc) : 2.0 * M * r * kc);
     return launch_gemm(c, main_part, dtype, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int lora_gemm_parts(const void* Am, const void* Bm, const void* bias, const void* Fp, const void* Qp, void* C,
+                               float* P_out, int64_t ldp, int64_t M, int Kc, int Nc, int r, int n_parts, int parts_on_k,
+                               float scale, int dtype, void* stream) {
+    if (M < 0 || Kc <= 0 || Nc <= 0 || r < 1 || r > kRP || n_parts < 2 || n_parts > 4) return LORA_E_BADARG;
+    if (dtype != LORA_F32 && dtype != LORA_F16 && dtype != LORA_BF16) return LORA_E_BADARG;
+    if (M == 0) return LORA_OK;
+    if (!Am || !Bm || !Fp || !Qp || !C || !P_out || ldp < (int64_t)n_parts * r) return LORA_E_BADARG;
+    const int split = parts_on_k ? Kc : Nc;  // the axis that is cut into parts
+    if (split % n_parts != 0) return LORA_E_BADARG;
+    const int part_n = split / n_parts;
+    if (dtype == LORA_F32 || (part_n % 64) != 0 || (Kc % 64) != 0 || (Nc % 8) != 0) return LORA_E_UNSUPPORTED;
+    if (!aligned16(Am) || !aligned16(Bm) || !aligned16(Fp) || !aligned16(Qp) || !aligned16(C) ||
+        (bias && (reinterpret_cast<uintptr_t>(bias) & 7u)))
+        return LORA_E_UNSUPPORTED;
+    GemmParams p{};
+    p.Am = Am; p.Bm = Bm; p.bias = bias; p.Fp = Fp; p.Qp = Qp; p.C = C; p.P = P_out;
+    p.M = M; p.Kc = Kc; p.Nc = Nc; p.r = r; p.scale = scale; p.lda = Kc; p.ldp = (int)ldp;
+    p.n_parts = n_parts; p.part_n = part_n; p.parts_on_k = parts_on_k ? 1 : 0;
+    const double e = 2.0;
+    ProfWork work(e * ((double)M * Kc + (double)Nc * Kc + (double)M * Nc) + e * r * (double)(Kc + Nc) * 1.0 + (bias ? e * Nc : 0.0),
+                  2.0 * M * (double)Kc * Nc + 2.0 * M * r * (double)(Kc + Nc));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!parts_on_k) return dtype == LORA_F16 ? launch_pipe<half_t, true>(p, s) : launch_pipe<bf16_t, true>(p, s);
+    if (n_parts != 3) return LORA_E_UNSUPPORTED;  // (the part-wise backward is instantiated for q / k / v groups)
+    return dtype == LORA_F16 ? launch_kparts<half_t, 3>(p, s) : launch_kparts<bf16_t, 3>(p, s);
 }

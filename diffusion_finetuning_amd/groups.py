@@ -88,7 +88,12 @@ class QKVGroup:
          Fa [16,K]   rows g·r+j = A_g[j,:]           (forward main-loop factor)
          Qb [3N,16]  row g·N+n, col g·r+j = B_g[n,j]  (forward epilogue factor, block diagonal)
          Fb [16,3N]  row g·r+j, col g·N+n = B_g[n,j]  (backward main-loop factor, block diagonal)
-         Qa [K,16]   row k, col g·r+j = A_g[j,k]      (backward epilogue factor)"""
+         Qa [K,16]   row k, col g·r+j = A_g[j,k]      (backward epilogue factor)
+    `wide` (3r > 16 rank slots — the ranks of BASELINE configs 3 and 5): every member keeps its own 16-slot factor pair and
+    the launch is `lora_gemm_parts` (column runs forward, contraction runs backward):
+         Fa [3][16,K]  part g: rows j < r = A_g        Qb [3N,16]    row g·N+n, col j < r = B_g[n,j]
+         Fb [16,3N]    row j < r, col g·N+n = B_g[n,j]  Qa [3][K,16]  part g: row k, col j < r = A_g[j,k]
+    T / U keep the [M, 3r] layout (member g in columns g·r ..) either way."""
 
     def __init__(self, layers, sinks):
         self.layers, self.sinks = list(layers), list(sinks)
@@ -96,6 +101,7 @@ class QKVGroup:
         self.K, self.N = lin.in_features, lin.out_features
         self.r = layers[0].lora_down.weight.shape[0]
         self.G = len(layers)
+        self.wide = self.G * self.r > RANK_PAD
         self.frozen = _FrozenCat(self.layers)
         self.Fa = self.Qb = self.Fb = self.Qa = None  # set by LoraSlab.enable_packed
 
@@ -109,11 +115,14 @@ class QKVGroup:
         r = layers[0].lora_down.weight.shape[0]
         # (biases: all members or none — the concatenated bias rides on the kernel's own bias argument; CLIP's projections
         #  carry one, the UNet's q/k/v do not)
-        return (len(layers) * r <= RANK_PAD and lin.in_features % 64 == 0 and lin.out_features % 64 == 0 and
+        fits = len(layers) * r <= RANK_PAD or (r <= RANK_PAD and len(layers) == 3)  # (the part-wise backward: three members)
+        return (fits and lin.in_features % 64 == 0 and lin.out_features % 64 == 0 and
                 all(l.linear.in_features == lin.in_features and l.linear.out_features == lin.out_features and
                     (l.linear.bias is None) == (lin.bias is None) and l.lora_down.weight.shape[0] == r for l in layers))
 
     def usable(self, x: torch.Tensor, cdtype: torch.dtype) -> bool:
+        if self.wide and cdtype == torch.float32:
+            return False  # the part-wise kernels are 16-bit (fp32 parity runs keep the members on their own)
         return (self.Fa is not None and self.Fa.dtype == cdtype and x.is_cuda and _same_scale(self.layers) is not None
                 and all(not l.linear.weight.requires_grad for l in self.layers))
 
@@ -135,7 +144,13 @@ class _QKVProjFn(torch.autograd.Function):
         qkv = torch.empty((M, N3), dtype=cdtype, device=x2.device)
         t = torch.empty((M, rr), dtype=torch.float32, device=x2.device)
         scale = _same_scale(group.layers)
-        nat.lora_gemm_packed(x2, K, w, group.frozen.bias(cdtype), group.Fa, group.Qb, None, None, 0, qkv, t, M, K, N3, rr, scale)
+        if group.wide:
+            if not nat.lora_gemm_parts(x2, w, group.frozen.bias(cdtype), group.Fa, group.Qb, qkv, t, rr, M, K, N3, group.r,
+                                       group.G, False, scale):
+                raise RuntimeError("grouped q/k/v forward: lora_gemm_parts has no kernel for this shape")
+        else:
+            nat.lora_gemm_packed(x2, K, w, group.frozen.bias(cdtype), group.Fa, group.Qb, None, None, 0, qkv, t, M, K, N3, rr,
+                                 scale)
         ctx.save_for_backward(x2, t)
         ctx.group, ctx.wt, ctx.scale = group, wt, scale
         ctx.x_shape, ctx.x_dtype = x.shape, x.dtype
@@ -155,22 +170,41 @@ class _QKVProjFn(torch.autograd.Function):
         M = d2.shape[0]
         need_dx = ctx.needs_input_grad[0]
         u = torch.empty((M, rr), dtype=torch.float32, device=d2.device)
+        u_by_part = False  # U layout: [M, 3r] (member g in columns g·r ..) or, from per-member launches, [3][M, r]
         dx2 = None
         if need_dx:
             if ctx.wt is None:
                 raise RuntimeError("grouped q/k/v backward: Wᵀ operand was not prepared in forward")
             dx2 = torch.empty((M, K), dtype=d2.dtype, device=d2.device)
-            nat.lora_gemm_packed(d2, N3, ctx.wt, None, g.Fb, g.Qa, None, None, 0, dx2, u, M, N3, K, rr, ctx.scale)
+            if g.wide:
+                if not nat.lora_gemm_parts(d2, ctx.wt, None, g.Fb, g.Qa, dx2, u, rr, M, N3, K, r, g.G, True, ctx.scale):
+                    raise RuntimeError("grouped q/k/v backward: lora_gemm_parts has no kernel for this shape")
+            else:
+                nat.lora_gemm_packed(d2, N3, ctx.wt, None, g.Fb, g.Qa, None, None, 0, dx2, u, M, N3, K, rr, ctx.scale)
+        elif g.wide:
+            # no dX wanted (the first block of a model: its input carries no gradient): U_g = dY_g·B_g from the members'
+            # own packed factors, one small launch each on the column slices of the shared gradient buffer
+            u, u_by_part = u.view(g.G, M, r), True
+            for i in range(g.G):
+                nat.lora_gemm_packed(d2[:, i * N:(i + 1) * N], N3, None, None, g.Fb_part[i], None, None, None, 0, None, u[i],
+                                     M, N, 0, r, ctx.scale)
         else:
             nat.lora_gemm_packed(d2, N3, None, None, g.Fb, None, None, None, 0, None, u, M, N3, 0, rr, ctx.scale)
         slab = g.sinks[0].slab
         stride = slab.stride
+        for sink in g.sinks:
+            slab.note_layer(sink.index, M, need_dx)
         for i, sink in enumerate(g.sinks):  # gB_i = s·dY_iᵀ·T_i : column slices of the shared buffers
             slab.defer(nat.grad_problem(d2, i * N, N3, N, t, i * r, rr, r, [sink.up_ptr], r, False, stride, M, ctx.scale),
                        sink.index, (d2, t))
-        # gA_cat = s·U_catᵀ·X, rank groups of r → the three `down` gradients, X read once
-        slab.defer(nat.grad_problem(x2, 0, K, K, u, 0, rr, rr, [s.down_ptr for s in g.sinks], r, True, stride, M, ctx.scale),
-                   None, (x2, u))
+        # gA = s·Uᵀ·X: as many members per problem as fit 16 accumulator columns (rank groups of r → their `down` gradients);
+        # all three at rank <= 5 — X read once — two + one at rank 8, one each at rank 16
+        per = 1 if u_by_part else max(1, RANK_PAD // r)
+        for c in range(0, g.G, per):
+            mem = g.sinks[c:c + per]
+            off, ld = (c * M * r, r) if u_by_part else (c * r, rr)
+            slab.defer(nat.grad_problem(x2, 0, K, K, u, off, ld, len(mem) * r, [s_.down_ptr for s_ in mem], r, True, stride,
+                                        M, ctx.scale), None, (x2, u))
         dx = None
         if need_dx:
             dx = dx2.view(ctx.x_shape)
@@ -371,6 +405,7 @@ class _CtxProjFn(torch.autograd.Function):
         slab = g.sinks[0].slab
         stride = slab.stride
         for i, sink in enumerate(g.sinks):
+            slab.note_layer(sink.index, M, False)
             slab.defer(nat.grad_problem(d2, g.off[i], g.total, g.N[i], t, i * M * r, r, r, [sink.up_ptr], r, False,
                                         stride, M, ctx.scale), sink.index, (d2, t))
             slab.defer(nat.grad_problem(e2, 0, g.K, g.K, u, i * M * r, r, r, [sink.down_ptr], r, True, stride, M,

@@ -290,7 +290,7 @@ def _lora_backward(ctx, x2, a, b, t, dy2):
         if sink is not None:
             # trainer mode: nothing is launched here — the two reductions join the slab's batched gradient launch
             # after backward, their row-block partials land in the model-wide partial slab (= the RCCL buffer's twin)
-            sink.defer_layer(dy2, x2, t, u, ctx.scale)
+            sink.defer_layer(dy2, x2, t, u, ctx.scale, need_dx)
         elif ctx.auto_sink is not None:
             # drop-in mode: the two reductions join ONE batched launch at the end of this backward pass (_AutoSink)
             down, up = ctx.params

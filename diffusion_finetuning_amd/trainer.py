@@ -49,10 +49,11 @@ class LayerSink:
         base = slab.partials.data_ptr()
         self.up_ptr, self.down_ptr = base + 4 * up_off, base + 4 * down_off
 
-    def defer_layer(self, dy2, x2, t, u, scale: float):
+    def defer_layer(self, dy2, x2, t, u, scale: float, need_dx: bool = True):
         M, N = dy2.shape
         K, r = x2.shape[1], t.shape[1]
         stride = self.slab.stride
+        self.slab.note_layer(self.index, M, need_dx)
         self.slab.defer(nat.grad_problem(dy2, 0, N, N, t, 0, r, r, [self.up_ptr], r, False, stride, M, scale), self.index,
                         (dy2, t))
         self.slab.defer(nat.grad_problem(x2, 0, K, K, u, 0, r, r, [self.down_ptr], r, True, stride, M, scale), None,
@@ -97,6 +98,7 @@ class LoraSlab:
         self.offsets = []
         self._pending, self._keep, self._ran = {}, [], {}
         self._range_tables = {}
+        self.layer_rows = {}  # layer index -> (rows M, dX produced) of its last backward (accounting: survey_work)
         self.qkv_groups, self.ctx_groups = [], []
         self.packed = None
         off = 0
@@ -186,6 +188,16 @@ class LoraSlab:
         group_views = []
         for grp in self.qkv_groups:
             K, N, r, G = grp.K, grp.N, grp.r, grp.G
+            if grp.wide:  # every member keeps its own 16-slot factors (groups.QKVGroup): Fa [G][16,K] | Qb [GN,16] | Fb [16,GN] | Qa [G][K,16]
+                fa, qb, fb, qa = off, off + 16 * G * K, off + 16 * G * K + 16 * G * N, off + 16 * G * K + 32 * G * N
+                for g, layer in enumerate(grp.layers):
+                    i = index_of[id(layer)]
+                    up_off, down_off = self.offsets[2 * i][0], self.offsets[2 * i + 1][0]
+                    rows.append([down_off, 0, K, r, fa + g * 16 * K, K, qa + g * 16 * K, 16])
+                    rows.append([up_off, 1, N, r, fb + g * N, G * N, qb + g * N * 16, 16])
+                group_views.append((grp, fa, qb, fb, qa))
+                off += 32 * G * (K + N)
+                continue
             fa, qb, fb, qa = off, off + 16 * K, off + 16 * K + 16 * G * N, off + 16 * K + 32 * G * N
             for g, layer in enumerate(grp.layers):
                 i = index_of[id(layer)]
@@ -215,12 +227,15 @@ class LoraSlab:
         pk = self.packed
         for layer, o, K, N in layer_views:
             layer.__dict__["_dfa_packed"] = (pk[o:o + 32 * K], pk[o + 32 * K:o + 32 * (K + N)])
+        for grp in self.qkv_groups:  # the members' own Bt16 [16,N] tiles (P-only launches of a wide group without dX)
+            grp.Fb_part = [l.__dict__["_dfa_packed"][1][:16 * grp.N] for l in grp.layers]
         for view in group_views:
             grp = view[0]
             if len(view) == 5:
                 _, fa, qb, fb, qa = view
                 K, GN = grp.K, grp.G * grp.N
-                grp.Fa, grp.Qb, grp.Fb, grp.Qa = pk[fa:fa + 16 * K], pk[qb:qb + 16 * GN], pk[fb:fb + 16 * GN], pk[qa:qa + 16 * K]
+                nk = 16 * K * (grp.G if grp.wide else 1)
+                grp.Fa, grp.Qb, grp.Fb, grp.Qa = pk[fa:fa + nk], pk[qb:qb + 16 * GN], pk[fb:fb + 16 * GN], pk[qa:qa + nk]
             else:
                 _, a16, b16, bt = view
                 grp.A16 = pk[a16:a16 + 16 * grp.G * grp.K]
@@ -232,6 +247,27 @@ class LoraSlab:
         """Refresh every packed factor from the fp32 master slab (one launch)."""
         if self.packed is not None:
             nat.lora_pack_items(self._pack_table, self._pack_table.shape[0], self._pack_maxlen, self.params, self.packed)
+
+    # -- accounting ------------------------------------------------------------------------------
+    def note_layer(self, index: int, rows: int, need_dx: bool):
+        self.layer_rows[index] = (int(rows), bool(need_dx))
+
+    def survey_work(self, esize: int = 2):
+        """Algorithmic bytes / flops of the LoRA layers that ran in the last step, by SURVEY §8(d)'s per-layer formulas
+        (reference operator lora_diffusion/lora.py:49-50 and its autograd): forward e·(MK+NK+MN) + e·r(K+N) (+ e·N bias),
+        backward e·(MN+MK) + (e+4)·r(K+N) + [e·(NK+MK) when dX is produced]; flops 2MKN + 2Mr(K+N) forward,
+        [2MKN] + 4Mr(K+N) + [2Mr(K+N)] backward.  Every operand counted ONCE per direction, whatever the kernels re-read."""
+        e = float(esize)
+        fb = bb = ff = bf = 0.0
+        for i, (M, dx) in self.layer_rows.items():
+            layer = self.layers[i]
+            r, K = layer.lora_down.weight.shape
+            N = layer.lora_up.weight.shape[0]
+            fb += e * (M * K + N * K + M * N) + e * r * (K + N) + (e * N if layer.linear.bias is not None else 0.0)
+            bb += e * (M * N + M * K) + (e + 4.0) * r * (K + N) + (e * (N * K + M * K) if dx else 0.0)
+            ff += 2.0 * M * K * N + 2.0 * M * r * (K + N)
+            bf += (2.0 * M * K * N if dx else 0.0) + 4.0 * M * r * (K + N) + (2.0 * M * r * (K + N) if dx else 0.0)
+        return {"layers": len(self.layer_rows), "fwd_bytes": fb, "bwd_bytes": bb, "fwd_flops": ff, "bwd_flops": bf}
 
     # -- factor gradients --------------------------------------------------------------------------
     def zero_grad(self):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LORA_HIP_ABI_VERSION 5
+#define LORA_HIP_ABI_VERSION 6
 
 enum lora_dtype { LORA_F32 = 0, LORA_F16 = 1, LORA_BF16 = 2 };
 
@@ -174,6 +174,24 @@ int lora_gemm_packed(const void* Am, int64_t lda, const void* Bm /* nullable wit
                      const int64_t* part_table /* nullable, device */, int n_parts, void* C /* nullable */,
                      float* P_out, int64_t M, int Kc, int Nc, int r, float scale, int64_t work_cols,
                      void* workspace /* nullable */, int64_t ws_bytes, int dtype, void* stream);
+
+/*
+ * The same contract for n_parts (2..4) LoraInjectedLinear layers of EQUAL shape that share an input, at any rank r <= 16 —
+ * attn1 to_q/to_k/to_v (and CLIPAttention q_proj/k_proj/v_proj) when 3r no longer fits one 16-slot factor, i.e. the ranks of
+ * BASELINE configs 3 (r = 8, train_lora_dreambooth.py:596-613) and 5 (r = 16, cli_lora_pti.py:693): three
+ * lora_diffusion/lora.py:49-50 forwards, or their three backward-input products summed, in ONE launch.  f16 / bf16.
+ *   parts_on_k == 0 (forward):  C[M,Nc] = Am·Bmᵀ + bias + s·P_g·Q_gᵀ on column run g = [g·Nc/n, (g+1)·Nc/n),
+ *       Am = X [M,Kc], Bm = [W_0; …] [Nc,Kc], Fp = [n_parts][16,Kc] (part g: rows j < r = A_g), Qp = [Nc,16] (row of part
+ *       g: columns j < r = B_g); P_out[m, g·r + j] = (X·A_gᵀ)[m, j], row stride ldp floats (>= n_parts·r).
+ *   parts_on_k == 1 (backward-input, n_parts == 3):  C[M,Nc] = Am·Bmᵀ + s·Σ_g P_g·Q_gᵀ with the CONTRACTION cut into runs,
+ *       Am = [dY_0 | …] [M,Kc], Bm = [W_0; …]ᵀ [Nc,Kc], Fp = [16,Kc] (column run g, rows j < r = B_gᵀ), Qp = [n_parts][Nc,16]
+ *       (part g: columns j < r = A_gᵀ); P_out[m, g·r + j] = (dY_g·B_g)[m, j].  No accumulation of three dX tensors.
+ * Unused rank rows / columns of Fp / Qp are zero.  LORA_E_UNSUPPORTED: f32, part width or Kc not a multiple of 64, operands
+ * not 16-byte aligned, parts_on_k with n_parts != 3 (the caller then runs the layers one by one).
+ */
+int lora_gemm_parts(const void* Am, const void* Bm, const void* bias /* nullable */, const void* Fp, const void* Qp,
+                    void* C, float* P_out, int64_t ldp, int64_t M, int Kc, int Nc, int r, int n_parts, int parts_on_k,
+                    float scale, int dtype, void* stream);
 
 /*
  * Backward w.r.t. the LoRA factors (no grad for W or b: lora.py:179-180 set requires_grad only on

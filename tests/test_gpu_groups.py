@@ -179,13 +179,91 @@ def test_grouped_projections_follow_the_ungrouped_trajectory(relerr):
     assert relerr(got, orc.flat_params(ref_params)) < 5e-3
 
 
-def test_context_group_alone_at_rank_8(relerr):
-    """Rank 8 (cfg-3): 3·8 > 16 rank slots, so q/k/v stay three launches, but the context K/V group (own factor rows
-    per part) still applies — and follows the ungrouped trajectory."""
-    t_g, got, lg = _train(True, True, dtype=torch.float16, r=8)
-    assert not t_g.slab.qkv_groups and len(t_g.slab.ctx_groups) == 1 and t_g.slab.ctx_groups[0]._pass is not None
-    _, want, lu = _train(False, True, dtype=torch.float16, r=8)
+@pytest.mark.parametrize("r", [8, 16])
+def test_grouped_projections_at_the_ranks_of_configs_3_and_5(relerr, r):
+    """Rank 8 (BASELINE config 3, train_lora_dreambooth.py:596-613) and 16 (config 5, cli_lora_pti.py:693): 3·r no longer fits
+    one 16-slot factor, so the q/k/v group runs as `lora_gemm_parts` — each member keeps its own factor pair, one launch
+    forward (column runs), one backward (contraction runs) — next to the context K/V group; the trajectory is the
+    ungrouped one and the fp32 CPU oracle's."""
+    t_g, got, lg = _train(True, True, dtype=torch.float16, r=r)
+    assert len(t_g.slab.qkv_groups) == 4 and all(g.wide and g.r == r for g in t_g.slab.qkv_groups)
+    assert len(t_g.slab.ctx_groups) == 1 and t_g.slab.ctx_groups[0]._pass is not None
+    _, want, lu = _train(False, True, dtype=torch.float16, r=r)
     assert relerr(lg, lu) < 2e-3 and relerr(got, want) < 2e-3, (relerr(lg, lu), relerr(got, want))
+    ref = _tiny64()
+    ref_params, _ = orc.inject(ref, r=r)
+    _warm(ref_params)
+    ref_losses = orc.train_steps(ref, ref_params, 4, 2, 8, 6, 64, lr=1e-3)
+    assert relerr(lg, torch.tensor(ref_losses)) < 5e-3, relerr(lg, torch.tensor(ref_losses))
+    assert relerr(got, orc.flat_params(ref_params)) < 5e-3, relerr(got, orc.flat_params(ref_params))
+    # recorded into a hipGraph and replayed: the same trajectory
+    t_r, got_r, lr_ = _train(True, True, dtype=torch.float16, r=r, graph=True)
+    assert t_r._graph is not None
+    assert relerr(lr_, lg) < 2e-3 and relerr(got_r, got) < 2e-3, (relerr(lr_, lg), relerr(got_r, got))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,K,N,r,bias", [(16384, 320, 320, 8, False), (4096, 640, 640, 16, False), (1024, 1280, 1280, 16, False),
+                                          (256, 1280, 1280, 8, False), (308, 768, 768, 8, True), (9216, 320, 320, 16, False),
+                                          (100, 64, 64, 6, True)])
+def test_gemm_parts_equals_the_three_layers_in_float64(close, relerr, dtype, M, K, N, r, bias):
+    """lora_gemm_parts — three equal LoraInjectedLinear layers on one input in ONE launch at ranks where 3r > 16 — against
+    the reference operator (lora.py:49-50) and its backward-input per layer in float64, on the q/k/v shapes of SD1.5 (cfg-3,
+    r = 8), SD2.1-768 (cfg-5, r = 16: 9216 rows), CLIP-L (biases, 308 ragged rows) and a ragged small case."""
+    g = torch.Generator().manual_seed(7)
+    G = 3
+    x = torch.randn(M, K, generator=g).to(dtype).to(DEV)
+    Ws = [((torch.rand(N, K, generator=g) * 2 - 1) / K ** 0.5).to(dtype) for _ in range(G)]
+    bs = [(torch.randn(N, generator=g) * 0.1).to(dtype) for _ in range(G)] if bias else None
+    As = [(torch.randn(r, K, generator=g) / r) for _ in range(G)]
+    Bs = [(torch.randn(N, r, generator=g) * 0.05) for _ in range(G)]
+    dY = torch.randn(M, G * N, generator=g).to(dtype).to(DEV)
+    params = torch.cat([t.reshape(-1) for pair in zip(Bs, As) for t in pair]).to(DEV)
+    fa, qb, fb, qa = 0, 16 * G * K, 16 * G * K + 16 * G * N, 16 * G * K + 32 * G * N
+    rows, po = [], 0
+    for i in range(G):
+        up_off, down_off = po, po + N * r
+        po += N * r + r * K
+        rows.append([down_off, 0, K, r, fa + i * 16 * K, K, qa + i * 16 * K, 16])
+        rows.append([up_off, 1, N, r, fb + i * N, G * N, qb + i * N * 16, 16])
+    packed = torch.full((32 * G * (K + N),), float("nan"), dtype=dtype, device=DEV)  # every element must be written by the pack
+    nat.lora_pack_items(torch.tensor(rows, dtype=torch.int64).to(DEV), len(rows), max(K, N), params, packed)
+    assert torch.isfinite(packed.float()).all()
+    Fa, Qb, Fb, Qa = packed[fa:qb], packed[qb:fb], packed[fb:qa], packed[qa:]
+    W = torch.cat(Ws).to(DEV)
+    Wt = W.t().contiguous()
+    bcat = torch.cat(bs).to(DEV) if bias else None
+    Y = torch.full((M, G * N), float("nan"), dtype=dtype, device=DEV)
+    T = torch.full((M, G * r), float("nan"), device=DEV)
+    assert nat.lora_gemm_parts(x, W, bcat, Fa, Qb, Y, T, G * r, M, K, G * N, r, G, False, 0.7)
+    dX = torch.full((M, K), float("nan"), dtype=dtype, device=DEV)
+    U = torch.full((M, G * r), float("nan"), device=DEV)
+    assert nat.lora_gemm_parts(dY, Wt, None, Fb, Qa, dX, U, G * r, M, G * N, K, r, G, True, 0.7)
+    tol = 2e-3 if dtype == torch.float16 else 1.5e-2
+    xd = x.double().cpu()
+    dx_ref = torch.zeros(M, K, dtype=torch.float64)
+    for i in range(G):
+        a, b = As[i].to(dtype).double(), Bs[i].to(dtype).double()  # the kernels multiply with the factors in the compute dtype
+        y_ref = orc.lora_linear_forward(xd, Ws[i].double(), bs[i].double() if bias else None, a, b, 0.7)
+        assert relerr(Y[:, i * N:(i + 1) * N].double().cpu(), y_ref) < tol, ("y", i)
+        close(Y[:, i * N:(i + 1) * N], y_ref, 8 * tol, ("y", i))
+        assert relerr(T[:, i * r:(i + 1) * r].double().cpu(), xd @ a.t()) < 1e-4, ("t", i)
+        dy_i = dY[:, i * N:(i + 1) * N].double().cpu()
+        dxi, _, _ = orc.lora_linear_backward(xd, Ws[i].double(), a, b, 0.7, dy_i)
+        dx_ref += dxi
+        assert relerr(U[:, i * r:(i + 1) * r].double().cpu(), dy_i @ b) < 1e-4, ("u", i)
+    assert relerr(dX.double().cpu(), dx_ref) < tol, relerr(dX.double().cpu(), dx_ref)
+    # the same numbers as the three per-layer launches give (their dX summed in fp32)
+    dx3 = torch.zeros(M, K, device=DEV)
+    for i in range(G):
+        y_i, t_i = nat.lora_linear_fwd(x, Ws[i].to(DEV), bs[i].to(DEV) if bias else None, As[i].to(DEV), Bs[i].to(DEV), 0.7)
+        close(Y[:, i * N:(i + 1) * N], y_i, tol, ("y vs per-layer", i))
+        close(T[:, i * r:(i + 1) * r], t_i, 1e-5, ("t vs per-layer", i))
+        dxi, u_i = nat.lora_linear_bwd_input(dY[:, i * N:(i + 1) * N].contiguous(), Ws[i].t().contiguous().to(DEV), As[i].to(DEV),
+                                             Bs[i].to(DEV), 0.7, True)
+        close(U[:, i * r:(i + 1) * r], u_i, 1e-5, ("u vs per-layer", i))
+        dx3 += dxi.float()
+    assert relerr(dX.float(), dx3) < tol
 
 
 def test_groups_under_gradient_checkpointing(relerr):
@@ -494,7 +572,8 @@ def test_full_size_cfg5_sd21_768_rank16_v_prediction_step_vs_cpu_oracle(relerr):
     set_use_memory_efficient_attention_xformers(unet, True)
     set_use_hip_geglu(unet, True)
     trainer = tr.LoraTrainer(unet, lr=1e-4, v_prediction=True)
-    assert not trainer.slab.qkv_groups and trainer.slab.ctx_groups[0].G == 32 and trainer.slab.ctx_groups[0].K == 1024
+    assert len(trainer.slab.qkv_groups) == 16 and all(g.wide for g in trainer.slab.qkv_groups)  # 3·16 rank slots: lora_gemm_parts
+    assert trainer.slab.ctx_groups[0].G == 32 and trainer.slab.ctx_groups[0].K == 1024
     assert trainer.slab.numel == 4 * 1246464 + 16 * 32 * 256  # r=16, and the 1024-wide (not 768) context side of 32 layers
     lat, noise, ts, ctx = orc.synthetic_batch(0, 1, 96, 77, 1024)
     loss = trainer.step(lat.to(DEV), noise.to(DEV), ts.to(DEV), ctx.to(DEV)).item()
@@ -622,6 +701,12 @@ def test_clip_attention_projections_share_one_launch(relerr, monkeypatch):
     t_r, got_r, lr_, _ = train(True, 4, graph=True)
     assert t_r._graph is not None
     assert relerr(lr_, lg) < 2e-3 and relerr(got_r, got) < 2e-3, (relerr(lr_, lg), relerr(got_r, got))
-    t_8, _, l8, calls_8 = train(True, 8)
-    assert not [g for g in t_8.slab.qkv_groups if g.layers[0].linear.bias is not None] and not calls_8  # 3·8 > 16 rank slots
+    # r = 8 (BASELINE config 3): 3·8 > 16 rank slots — the CLIP group runs as lora_gemm_parts (not lora_gemm_packed) and
+    # follows the ungrouped trajectory
+    t_8, got8, l8, calls_8 = train(True, 8)
+    clip8 = [g for g in t_8.slab.qkv_groups if g.layers[0].linear.bias is not None]
+    assert len(clip8) == 2 and all(g.wide for g in clip8)
+    assert not calls_8  # no 3·64-wide lora_gemm_packed launch: the wide group goes through lora_gemm_parts
+    _, want8, lu8, _ = train(False, 8)
+    assert relerr(l8, lu8) < 2e-3 and relerr(got8, want8) < 2e-3, (relerr(l8, lu8), relerr(got8, want8))
     assert torch.isfinite(l8).all()
