@@ -79,6 +79,8 @@ SIGNATURES = {
     "ddpm_add_noise": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
     "ddpm_noise_prologue": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, ctypes.c_uint64, ctypes.c_uint64,
                                    _i32, _i32, _vp]),
+    "embed_rows_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i32, _vp]),
+    "embed_rows_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i32, _i32, _vp]),
     "geglu_linear_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "geglu_gate_fwd": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "geglu_gate_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
@@ -538,6 +540,27 @@ def ddpm_noise_prologue(x0, sqrt_acp, sqrt_1macp, out_dtype: torch.dtype, seed: 
     return (noisy, target, t, eps) if want_draw else (noisy, target, t)
 
 
+def embed_rows_fwd(table, ids, out_dtype: torch.dtype):
+    """table [V,D] fp32, ids int64 (any shape) → rows [*ids.shape, D] in out_dtype (include/lora_hip.h: embed_rows_fwd)."""
+    _require_device(table, ids)
+    V, D = table.shape
+    flat = ids.reshape(-1)
+    flat = flat if flat.is_contiguous() else flat.contiguous()
+    out = torch.empty((flat.numel(), D), dtype=out_dtype, device=table.device)
+    _check(lib().embed_rows_fwd(_ptr(table), _ptr(flat), _ptr(out), flat.numel(), D, V, dtype_code(out_dtype), _stream(table)),
+           "embed_rows_fwd")
+    return out.view(*ids.shape, D)
+
+
+def embed_rows_bwd(d_rows, ids, grad_table, accumulate: bool = False) -> None:
+    """grad_table[t] (+)= Σ of the rows d_rows[p] with ids[p] == t, positions in ascending order (deterministic)."""
+    _require_device(d_rows, ids, grad_table)
+    V, D = grad_table.shape
+    assert d_rows.is_contiguous() and ids.is_contiguous() and d_rows.numel() == ids.numel() * D
+    _check(lib().embed_rows_bwd(_ptr(d_rows), _ptr(ids), _ptr(grad_table), ids.numel(), D, V, dtype_code(d_rows.dtype),
+                                int(accumulate), _stream(d_rows)), "embed_rows_bwd")
+
+
 def geglu_gate_fwd(y2):
     """y2 [M, 2C] contiguous → h·gelu(g) [M, C]."""
     _require_device(y2)
@@ -560,20 +583,30 @@ _zero_factors = {}
 _zero_factors_retired = []
 
 
+def zero_factor_buffer(n_elems: int, dtype: torch.dtype, device):
+    """A zeroed buffer of >= n_elems elements for launches without a rank-r term (a zero [16, Kc] factor tile and a zero
+    [Nc, 16] epilogue factor); one per (device, dtype), grown on demand.  None inside a recording when it would have to be
+    allocated (never allocate-and-zero under capture); an outgrown buffer stays alive — a recorded hipGraph may still read it."""
+    key = (device, dtype)
+    z = _zero_factors.get(key)
+    if z is None or z.numel() < n_elems:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        if z is not None:
+            _zero_factors_retired.append(z)
+        z = _zero_factors[key] = torch.zeros(max(n_elems, 16 * 10240), dtype=dtype, device=device)
+    return z
+
+
 def geglu_linear_bwd(dz2, w2t, y2):
     """Backward of `z = (h·gelu(g)) @ W2ᵀ + b2` w.r.t. y = [h | g] in ONE launch (the gate's backward rides in the epilogue
     of dout = dz·W2): dz2 [M,Nz], w2t = W2ᵀ [F,Nz], y2 [M,2F] → dY [M,2F]; None when the library has no fused kernel."""
     _require_device(dz2, w2t, y2)
     M, Nz = dz2.shape
     F = w2t.shape[0]
-    key = (dz2.device, dz2.dtype)
-    z = _zero_factors.get(key)
-    if z is None or z.numel() < 16 * max(Nz, F):
-        if torch.cuda.is_current_stream_capturing():
-            return None  # (never allocate-and-zero inside a recording: the caller runs the two-launch form)
-        if z is not None:
-            _zero_factors_retired.append(z)  # a recorded hipGraph may still read the old buffer: it stays alive (and zero)
-        z = _zero_factors[key] = torch.zeros(16 * max(Nz, F, 10240), dtype=dz2.dtype, device=dz2.device)
+    z = zero_factor_buffer(16 * max(Nz, F), dz2.dtype, dz2.device)
+    if z is None:
+        return None  # (the caller runs the two-launch form)
     dy = torch.empty_like(y2)
     st = lib().geglu_linear_bwd(_ptr(dz2), _ptr(w2t), _ptr(y2), _ptr(dy), _ptr(z), M, Nz, F, dtype_code(dz2.dtype) if dz2.dtype != torch.float32 else 0,
                                 _stream(dz2))

@@ -291,7 +291,9 @@ class _CtxPass:
 
 class CtxKVGroup:
     """to_k / to_v of every cross-attention module that projects the same encoder_hidden_states.  Part 2i = to_k and
-    part 2i+1 = to_v of module i; columns [off[g], off[g] + N[g]) of the [M, ΣN] buffers belong to part g."""
+    part 2i+1 = to_v of module i; columns [off[g], off[g] + N[g]) of the [M, ΣN] buffers belong to part g.  Forward: one
+    launch per pass.  Backward: one P-only launch for the factors' U = dY·B of every part, and — when the context itself
+    carries a gradient (a training text encoder / training token embeddings) — one launch for its dX."""
 
     def __init__(self, modules, layers, sinks):
         self.modules, self.layers, self.sinks = list(modules), list(layers), list(sinks)
@@ -343,8 +345,10 @@ class CtxKVGroup:
         # (per-module path); the reentrant form's no-grad forward and every ordinary pass use the group.
         if _in_backward() or _saved_tensor_hooks_active():
             return False
+        # (a context that carries a gradient — a text encoder that trains, train_lora_dreambooth.py:608-621, or whose token
+        #  embeddings do, cli_lora_pti.py:706-722 — gets its dX from ONE grouped launch as well: _CtxProjFn.backward)
         return (self.A16 is not None and self.A16.dtype == cdtype and ctx_t.is_cuda and ctx_t.dim() == 3 and
-                ctx_t.shape[-1] == self.K and not ctx_t.requires_grad and _same_scale(self.layers) is not None and
+                ctx_t.shape[-1] == self.K and _same_scale(self.layers) is not None and
                 all(not l.linear.weight.requires_grad for l in self.layers))
 
     def tables(self, device, M: int):
@@ -380,7 +384,7 @@ class _CtxProjFn(torch.autograd.Function):
         if not e2.is_contiguous():
             e2 = e2.contiguous()
         M = e2.shape[0]
-        w, _ = group.frozen.get(cdtype, False)
+        w, _ = group.frozen.get(cdtype, ctx.needs_input_grad[0])  # Wᵀ only when the context wants a gradient
         tile_part, _ = group.tables(e2.device, M)
         kv = torch.empty((M, group.total), dtype=cdtype, device=e2.device)
         t = torch.empty((group.G, M, group.r), dtype=torch.float32, device=e2.device)
@@ -389,6 +393,7 @@ class _CtxProjFn(torch.autograd.Function):
                              group.r, scale)
         ctx.save_for_backward(e2, t)
         ctx.group, ctx.scale = group, scale  # (not `state`: state → kv → this node would be a reference cycle)
+        ctx.e_shape, ctx.e_dtype = ehs.shape, ehs.dtype
         return kv
 
     @staticmethod
@@ -402,15 +407,32 @@ class _CtxProjFn(torch.autograd.Function):
         u = torch.empty((g.G, M, r), dtype=torch.float32, device=e2.device)
         nat.lora_gemm_packed(d2, g.total, None, None, g.Bt16, None, None, part_table, g.G, None, u, M, 64, 0, r,
                              ctx.scale, work_cols=g.total)
+        need_dx = ctx.needs_input_grad[0]
+        de = None
+        if need_dx:
+            # d(context) = Σ_g dKV_g·W_g + s·Σ_g U_g·A_g — the dX of all G projections at once, no per-layer launches and no
+            # G-1 accumulations: ONE fused-GEMM launch over the concatenated contraction (dKV [M, ΣN] · [W_0; W_1; …], split
+            # over K inside the launch: M is only batch × 77 rows) plus the rank-(G·r) product of the U the launch above left
+            # ([M, G·r]·[G·r, K], a plain library GEMM on the fp32 masters)
+            _, wt = g.frozen.get(d2.dtype, True)
+            zeros = nat.zero_factor_buffer(16 * max(g.total, g.K), d2.dtype, d2.device)
+            if zeros is None:
+                raise RuntimeError("grouped context projection backward: run one host-launched step before recording (the "
+                                   "zero-factor buffer is allocated outside a recording)")
+            de2 = torch.empty((M, g.K), dtype=d2.dtype, device=d2.device)
+            nat.lora_gemm_packed(d2, g.total, wt, None, zeros, zeros, None, None, 0, de2, None, M, g.total, g.K, 1, 0.0)
+            acat = torch.cat([l.lora_down.weight.detach().float() for l in g.layers])      # [G·r, K]
+            de = torch.addmm(de2.float(), u.permute(1, 0, 2).reshape(M, g.G * r), acat, alpha=ctx.scale)
+            de = de.to(ctx.e_dtype).view(ctx.e_shape)
         slab = g.sinks[0].slab
         stride = slab.stride
         for i, sink in enumerate(g.sinks):
-            slab.note_layer(sink.index, M, False)
+            slab.note_layer(sink.index, M, need_dx)
             slab.defer(nat.grad_problem(d2, g.off[i], g.total, g.N[i], t, i * M * r, r, r, [sink.up_ptr], r, False,
                                         stride, M, ctx.scale), sink.index, (d2, t))
             slab.defer(nat.grad_problem(e2, 0, g.K, g.K, u, i * M * r, r, r, [sink.down_ptr], r, True, stride, M,
                                         ctx.scale), None, (e2, u))
-        return (None, None, None, None) + (None,) * (2 * g.G)
+        return (de, None, None, None) + (None,) * (2 * g.G)
 
 
 class _CtxAttnKVFn(torch.autograd.Function):

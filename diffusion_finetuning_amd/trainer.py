@@ -69,7 +69,10 @@ class LoraSlab:
     far in a few chip-filling launches (the operands — every layer's dY and X — simply stay alive until then: 288 GB of
     HBM) and folds the row-block partial sums of the layers that ran into the gradient slab, in block order."""
 
-    def __init__(self, models: Sequence[nn.Module]):
+    def __init__(self, models: Sequence[nn.Module], dense_params: Sequence[nn.Parameter] = ()):
+        """dense_params: trainable non-LoRA Parameters that ride in the same flat buffers BEHIND the LoRA region (the token
+        embedding table of a text encoder whose input embeddings train, cli_lora_pti.py:706-722): same clip norm, same
+        fused AdamW, their own learning-rate range — but no partial-sum slab and no place in the LoRA gradient exchange."""
         self._sinks = []
         self.layers: List[LoraInjectedLinear] = []
         self.model_ranges: List[Tuple[int, int]] = []
@@ -89,8 +92,19 @@ class LoraSlab:
         self.numel = total
         self.stride = total + pad
         self.device = device
-        self.params = torch.zeros(total + pad, dtype=torch.float32, device=device)
-        self.grads = torch.zeros(total + pad, dtype=torch.float32, device=device)
+        self.dense_ranges: List[Tuple[int, int]] = []
+        tail = 0
+        for q in dense_params:
+            self.dense_ranges.append((self.stride + tail, self.stride + tail + q.numel()))
+            tail += (q.numel() + 3) // 4 * 4
+        self.total = self.stride + tail  # LoRA region (padded) + dense tail: what the clip norm and the optimizer cover
+        self.params = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(self.total, dtype=torch.float32, device=device)
+        for q, (a, b) in zip(dense_params, self.dense_ranges):
+            view = self.params[a:b].view(q.shape)
+            view.copy_(q.detach().float())
+            q.data = view
+            q.grad = self.grads[a:b].view(q.shape)
         # row-block partial sums of the factor gradients, [blocks][slab]: written by the gradient kernel with plain
         # stores, summed in block order by the fold (deterministic, no atomics).  Never needs zeroing: a layer's blocks
         # are fully rewritten whenever it runs, and only layers that ran are folded.
@@ -345,7 +359,9 @@ class FusedClipAdamW:
         does not count, like torch.cuda.amp.GradScaler never calls optimizer.step() for it."""
         s = self.slab
         self.step_count += 1
-        nat.lora_grad_sqnorm(s.grads[: s.numel], grad_mul, self.norm)
+        # (one norm over everything that trains: clip_grad_norm_ over chain(unet.parameters(), text_encoder.parameters()),
+        #  cli_lora_pti.py:448-450; the padding between the LoRA region and a dense tail is zero)
+        nat.lora_grad_sqnorm(s.grads[: s.numel] if s.total == s.stride else s.grads, grad_mul, self.norm)
         for g in self.groups:
             a, b = g["range"]
             if b <= a:
@@ -467,6 +483,76 @@ class LossScaler:
         return self.scale != before
 
 
+class _TokenRowsFn(torch.autograd.Function):
+    """rows = table[ids] (nn.Embedding.forward of the text encoder's token table) through the HIP gather; backward hands the
+    incoming gradient rows to the TokenTable, which sums them per token in a fixed order after the exchange — the table's
+    `.grad` is never produced by autograd."""
+
+    @staticmethod
+    def forward(ctx, ids, weight, table, out_dtype):
+        ctx.table = table
+        ctx.ids = ids
+        return nat.embed_rows_fwd(weight.detach(), ids, out_dtype)
+
+    @staticmethod
+    def backward(ctx, d_rows):
+        t = ctx.table
+        rows = d_rows.reshape(-1, t.D)
+        t._pending.append((ctx.ids.reshape(-1).contiguous(), rows if rows.is_contiguous() else rows.contiguous()))
+        return None, None, None, None
+
+
+class TokenTable:
+    """The input-embedding table of a text encoder whose token embeddings train next to the LoRA factors: the tuning phase
+    of lora_diffusion/cli_lora_pti.py with continue_inversion (default, :528) — `text_encoder.get_input_embeddings()
+    .parameters()` in the optimizer (:706-722), everything else of the encoder frozen.  The fp32 master lives in the slab's
+    dense tail (clip + AdamW like every other trainable); the module's forward is the HIP gather; the gradient rows of the
+    tokens that occurred are summed per token in position order (`embed_rows_bwd`) — after an all-gather of (ids, rows) in
+    rank order under data parallelism, so every replica adds the same numbers in the same order and only B·L rows (not the
+    200-MB table gradient) cross the GPUs."""
+
+    def __init__(self, slab: "LoraSlab", text_encoder: nn.Module, index: int, out_dtype: torch.dtype):
+        import functools
+
+        self.module = text_encoder.get_input_embeddings()
+        w = self.module.weight
+        self.V, self.D = w.shape
+        self.range = slab.dense_ranges[index]
+        a, b = self.range
+        self.grad = slab.grads[a:b].view(self.V, self.D)
+        self.out_dtype = out_dtype
+        self._pending = []
+        if "forward" not in self.module.__dict__:
+            self.module.__dict__["_dfa_original_forward"] = self.module.forward
+        self.module.forward = functools.partial(self._forward, self.module)
+
+    def _forward(self, module, input_ids):
+        dt = torch.get_autocast_dtype("cuda") if (torch.is_autocast_enabled("cuda") and self.out_dtype != torch.float32) \
+            else self.out_dtype
+        if not module.weight.requires_grad or not torch.is_grad_enabled():
+            return nat.embed_rows_fwd(module.weight.detach(), input_ids, dt)
+        return _TokenRowsFn.apply(input_ids, module.weight, self, dt)
+
+    def begin_pass(self):
+        self._pending = []
+
+    def collect(self, pg, world: int):
+        """Table gradient of the passes since begin_pass(): rows of the tokens that occurred, summed in position order."""
+        for k, (ids, rows) in enumerate(self._pending):
+            if world > 1:
+                all_ids = [torch.empty_like(ids) for _ in range(world)]
+                all_rows = [torch.empty_like(rows) for _ in range(world)]
+                dist.all_gather(all_ids, ids, group=pg)
+                dist.all_gather(all_rows, rows, group=pg)
+                ids, rows = torch.cat(all_ids), torch.cat(all_rows)
+            nat.embed_rows_bwd(rows, ids, self.grad, accumulate=k > 0)
+
+    def detach(self):
+        orig = self.module.__dict__.pop("_dfa_original_forward", None)
+        if orig is not None:
+            del self.module.forward
+
+
 class LoraTrainer:
     """One object per process (= per GPU).  `step()` runs one full training step and returns the loss tensor
     (no host sync unless the caller reads it)."""
@@ -474,7 +560,7 @@ class LoraTrainer:
     def __init__(self, unet: nn.Module, text_encoder: Optional[nn.Module] = None, lr=1e-4, lr_text=5e-6,
                  weight_decay=1e-2, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0, loss_scale: Optional[float] = None,
                  v_prediction=False, process_group=None, always_reduce=False, capture_graph=False,
-                 group_projections=True):
+                 group_projections=True, lr_embed: float = 5e-4, weight_decay_embed: Optional[float] = None):
         """capture_graph: record add_noise → [text encoder] → UNet forward → loss → backward → factor gradients of a step
         once into a hipGraph and replay it on later steps with the same shapes (inputs are copied into static buffers).
         The gradient exchange and the optimizer stay outside the graph, so no collective is ever captured.  A step with a
@@ -482,21 +568,34 @@ class LoraTrainer:
         step, train_lora_dreambooth.py:840); a mask is a static input like the latents.  Anything else runs host-launched.
         group_projections: run attn1 to_q/to_k/to_v as one launch per block and the attn2 to_k/to_v of all blocks as one
         launch per pass (groups.py; effective for attention modules switched to the HIP cores with the reference's
-        `set_use_memory_efficient_attention_xformers`)."""
+        `set_use_memory_efficient_attention_xformers`).
+        Token embeddings: when `text_encoder.get_input_embeddings().weight.requires_grad` is set — what the PTI tuning phase
+        does under continue_inversion (cli_lora_pti.py:706-722) — the table trains too, with `lr_embed` (continue_inversion_lr /
+        learning_rate_ti, :713-715) and `weight_decay_embed` (default: `weight_decay`, one AdamW for all groups, :738)."""
         self.unet, self.text_encoder = unet, text_encoder
         self.capture_graph = bool(capture_graph)
         self._graph = None
         models = [unet] + ([text_encoder] if text_encoder is not None and lora_layers(text_encoder) else [])
-        self.trains_text_encoder = len(models) > 1
-        self.slab = LoraSlab(models)
+        emb = text_encoder.get_input_embeddings() if (text_encoder is not None and hasattr(text_encoder, "get_input_embeddings")) \
+            else None
+        train_emb = emb is not None and emb.weight.requires_grad
+        self.trains_text_encoder = len(models) > 1 or train_emb
+        self.slab = LoraSlab(models, [emb.weight] if train_emb else [])
         if group_projections:
             self.slab.enable_groups()
         groups = [{"range": self.slab.model_ranges[0], "lr": lr, "weight_decay": weight_decay}]
         if len(models) > 1:
             groups.append({"range": self.slab.model_ranges[1], "lr": lr_text, "weight_decay": weight_decay})
+        if train_emb:
+            groups.append({"range": self.slab.dense_ranges[0], "lr": lr_embed,
+                           "weight_decay": weight_decay if weight_decay_embed is None else weight_decay_embed})
         self.opt = FusedClipAdamW(self.slab, groups, betas, eps, max_grad_norm)
         self.device = self.slab.params.device
         self.dtype = next(p for p in unet.parameters() if p.dim() == 4).dtype  # conv weight dtype = compute dtype
+        self.token_table = None
+        if train_emb:
+            te_dtype = next((p.dtype for n_, p in text_encoder.named_parameters() if p is not emb.weight), torch.float32)
+            self.token_table = TokenTable(self.slab, text_encoder, 0, te_dtype)
         initial = float(loss_scale) if loss_scale is not None else (1024.0 if self.dtype == torch.float16 else 1.0)
         self.scaler = LossScaler(initial, self.GROWTH_INTERVAL)
         self._warned_overflow = False
@@ -667,10 +766,14 @@ class LoraTrainer:
             noisy, target = nat.ddpm_add_noise(latents, noise, timesteps, self.sqrt_acp, self.sqrt_1macp, self.dtype,
                                                self.v_prediction)
         self.exchange.arm()
+        if self.token_table is not None:
+            self.token_table.begin_pass()
         ehs = self._conditioning(encoder_hidden_states, input_ids)
         loss = self._forward_backward(noisy, target, timesteps, ehs, with_prior_preservation, prior_loss_weight,
                                       self._raw_mask(mask, latents))
         self.exchange.finish()
+        if self.token_table is not None:
+            self.token_table.collect(self.pg, self.world if self.exchange.active else 1)
         self.opt.step(grad_mul=1.0 / (self.world * self.loss_scale))
         self._watch_overflow()
         self.slab.repack()  # forwards outside step() (sampling, evaluation, saving merged weights) see the new factors
@@ -684,6 +787,8 @@ class LoraTrainer:
         else:
             noisy, target = nat.ddpm_add_noise(st["latents"], st["noise"], st["timesteps"], self.sqrt_acp,
                                                self.sqrt_1macp, self.dtype, self.v_prediction)
+        if self.token_table is not None:
+            self.token_table.begin_pass()  # (runs while recording: the rows buffer it ends up holding is the recording's own)
         ehs = self._conditioning(st["ehs"], st["ids"])
         st["loss"] = self._forward_backward(noisy, target, st["timesteps"], ehs, st["prior"], st["prior_weight"], st["mask"])
 
@@ -759,6 +864,8 @@ class LoraTrainer:
             self._graph_inputs(st, latents, noise, timesteps, ehs, ids, mask, seed)
         st["graph"].replay()
         self.exchange.finish()
+        if self.token_table is not None:
+            self.token_table.collect(self.pg, self.world if self.exchange.active else 1)
         self.opt.step(grad_mul=1.0 / (self.world * self.loss_scale))
         self._watch_overflow()
         self.slab.repack()

@@ -364,6 +364,20 @@ int attn_merge_heads_strided(const void* src, void* dst, int B, int N, int H, in
                              int64_t sN, int dtype, void* stream);
 
 /*
+ * Token-embedding rows for a text encoder whose INPUT EMBEDDINGS train next to the UNet's LoRA factors: the tuning phase of
+ * lora_diffusion/cli_lora_pti.py with continue_inversion (default, :528) puts `text_encoder.get_input_embeddings().parameters()`
+ * in the optimizer (:706-722) and runs `text_encoder(batch["input_ids"])[0]` inside loss_step (:199-206) — BASELINE config 5,
+ * "+ extended-latent TI".  They replace `torch.nn.Embedding.forward` / its backward for that one table (fp32 master [V, D]).
+ *   embed_rows_fwd : out[p, :] = table[ids[p], :] cast to out_dtype, p < n (ids int64; out of range ids are clamped).
+ *   embed_rows_bwd : grad_table[t, :] (+)= Σ_{p : ids[p] == t} dE[p, :] for every token t that occurs, the positions added in
+ *                    ascending order by ONE owner workgroup (torch's scatter uses atomics: run-to-run sum order).  Rows of tokens
+ *                    that do not occur are not touched.  dE in `dtype`; accumulate = 0 overwrites the rows that occur.
+ */
+int embed_rows_fwd(const float* table, const int64_t* ids, void* out, int64_t n, int D, int64_t V, int out_dtype, void* stream);
+int embed_rows_bwd(const void* dE, const int64_t* ids, float* grad_table, int64_t n, int D, int64_t V, int dtype,
+                   int accumulate, void* stream);
+
+/*
  * Short-context attention core  O = softmax(Q·Kᵀ·scale)·V  per head, for at most 128 keys: the cross-attention
  * (`attn2`) between the to_q/to_k/to_v and to_out LoRA linears (diffusers CrossAttention.forward, the
  * caller of the layers wrapped by lora_diffusion/lora.py:137-183).  Tensors keep the layout those linears produce

@@ -217,13 +217,15 @@ def adamw_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_de
 # ------------------------------------------------------------------------------------------------
 # row H: the step harness (train_lora_dreambooth.py:811-888), synthetic latents instead of VAE/CLIP
 # ------------------------------------------------------------------------------------------------
-def synthetic_batch(step: int, batch: int, latent_hw: int, ctx_len: int, ctx_dim: int, seed_base: int = 1000):
+def synthetic_batch(step: int, batch: int, latent_hw: int, ctx_len: int, ctx_dim: int, seed_base: int = 1000,
+                    t_max: int = 1000):
     """Per-step synthetic inputs, identical on every rank (set_seed semantics, train_lora_dreambooth.py:509-510)
-    and on CPU/GPU (generated on the host, copied)."""
+    and on CPU/GPU (generated on the host, copied).  t_max: exclusive bound of the timestep draw (the PTI loop draws below
+    int(1000 · t_mutliplier), cli_lora_pti.py:190-195)."""
     g = torch.Generator().manual_seed(seed_base + step)
     latents = torch.randn(batch, 4, latent_hw, latent_hw, generator=g) * 0.18215
     noise = torch.randn(batch, 4, latent_hw, latent_hw, generator=g)
-    t = torch.randint(0, 1000, (batch,), generator=g)
+    t = torch.randint(0, t_max, (batch,), generator=g)
     ctx = torch.randn(batch, ctx_len, ctx_dim, generator=g)
     return latents, noise, t, ctx
 
@@ -257,6 +259,69 @@ def train_steps(unet, params: List[torch.Tensor], steps: int, batch: int, latent
             with torch.no_grad():
                 adamw_step(p, g, mm, vv, s - first_step + 1, lr, weight_decay=weight_decay)
         losses.append(sum(step_losses) / world)
+    return losses
+
+
+# ------------------------------------------------------------------------------------------------
+# config 5: the PTI tuning phase with continue_inversion (cli_lora_pti.py:408-451, loss_step :170-248, set-up :693-738)
+# ------------------------------------------------------------------------------------------------
+def freeze_all_but_token_embeddings(text_encoder) -> nn.Parameter:
+    """cli_lora_pti.py:704-722: requires_grad_(False); under continue_inversion requires_grad_(True) and then the encoder
+    layers, the final layer norm and the position embedding frozen again — what is left trainable is the token table
+    (`get_input_embeddings().parameters()`, the optimizer group of :708-716).  Returns that Parameter."""
+    text_encoder.requires_grad_(False)
+    table = text_encoder.get_input_embeddings().weight
+    table.requires_grad_(True)
+    return table
+
+
+def synthetic_token_ids(step: int, batch: int, ctx_len: int, vocab: int, seed_base: int = 7000, bos: int = 1, eos: int = 2):
+    """Caption-shaped ids: bos, a few words, then eos repeated to the end (the tokenizer pads with one token: every padding
+    position hits the SAME table row, so the table gradient sums many positions per token)."""
+    g = torch.Generator().manual_seed(seed_base + step)
+    ids = torch.randint(3, vocab, (batch, ctx_len), generator=g)
+    n_words = torch.randint(1, max(2, ctx_len - 2), (batch,), generator=g)
+    ids[:, 0] = bos
+    for b in range(batch):
+        ids[b, 1 + int(n_words[b]):] = eos
+    return ids
+
+
+def pti_tuning_steps(unet, text_encoder, lora_params: List[torch.Tensor], steps: int, batch: int, latent_hw: int,
+                     ctx_len: int, vocab: int, lr_unet=1e-4, lr_embed=5e-4, weight_decay=1e-3, max_grad_norm=1.0,
+                     v_prediction=True, t_multiplier=0.8, masks: Optional[Sequence[torch.Tensor]] = None, first_step: int = 0,
+                     bos: int = 1, eos: int = 2):
+    """`steps` iterations of perform_tuning (cli_lora_pti.py:424-451) with the optimizer of :738 —
+    AdamW([{unet LoRA, lr_unet}, {token table, continue_inversion_lr | ti_lr}], weight_decay=weight_decay_lora) — on synthetic
+    latents: loss_step's draw `randint(0, int(1000·t_mutliplier))` (:190-195, 0.8 at :444), add_noise, the text encoder INSIDE
+    the step (:199-206), ε- or v-target (:215-220), optional mask (:222-245), mse (:247); backward; clip_grad_norm_ over
+    chain(unet.parameters(), text_encoder.parameters()) (:448-450); step.  fp32 (the reference autocasts; the parity target
+    is the fp32 arithmetic).  Returns the loss history; `lora_params` and the token table are updated in place."""
+    acp = ddpm_alphas_cumprod()
+    table = text_encoder.get_input_embeddings().weight
+    params = list(lora_params) + [table]
+    lrs = [lr_unet] * len(lora_params) + [lr_embed]
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+    ctx_dim = table.shape[1]
+    losses = []
+    for s in range(first_step, first_step + steps):
+        latents, noise, t, _ = synthetic_batch(s, batch, latent_hw, ctx_len, ctx_dim, t_max=int(1000 * t_multiplier))
+        ids = synthetic_token_ids(s, batch, ctx_len, vocab, bos=bos, eos=eos)
+        for p in params:
+            p.grad = None
+        noisy = add_noise(latents, noise, t, acp)
+        ehs = text_encoder(ids)[0]
+        pred = unet(noisy, t, ehs).sample
+        target = get_velocity(latents, noise, t, acp) if v_prediction else noise
+        loss = masked_mse_loss(pred, target, masks[s - first_step]) if masks is not None else mse_loss(pred, target)
+        loss.backward()
+        grads = [p.grad for p in params]
+        clip_grad_norm(grads, max_grad_norm)
+        for p, g, mm, vv, lr in zip(params, grads, m, v, lrs):
+            with torch.no_grad():
+                adamw_step(p, g, mm, vv, s - first_step + 1, lr, weight_decay=weight_decay)
+        losses.append(loss.item())
     return losses
 
 

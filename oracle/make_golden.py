@@ -275,6 +275,67 @@ def gen_trajectory(ref):
     save_file(tensors, os.path.join(OUT, "trajectory.safetensors"), meta)
 
 
+def gen_pti_trajectory(ref):
+    """BASELINE config 5's second half — the PTI tuning phase with continue_inversion (cli_lora_pti.py:693-753): the REFERENCE's
+    inject_trainable_lora on the tiny UNet, the token table of a tiny transformers CLIPTextModel as the second AdamW group
+    (:706-722,738), loss_step's arithmetic (:170-248: draw below int(1000·0.8), text encoder inside the step, v-prediction
+    target, mse), clip_grad_norm_ over chain(unet.parameters(), text_encoder.parameters()) (:448-450).  cli_lora_pti.py itself
+    needs diffusers / fire / wandb and cannot be imported here: the loop below is its step spelled with the same torch calls
+    around the reference's own LoRA modules."""
+    from transformers import CLIPTextConfig, CLIPTextModel
+
+    from oracle import lora_oracle as orc
+
+    vocab, ctx_len, steps, batch = 60, 8, 8, 2
+    torch.manual_seed(21)
+    te = CLIPTextModel(CLIPTextConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=2,
+                                      vocab_size=vocab, max_position_embeddings=ctx_len, bos_token_id=1, eos_token_id=2,
+                                      pad_token_id=0))
+    unet = build_tiny_unet(seed=3)
+    params, _ = ref.inject_trainable_lora(unet, r=4)                     # :693
+    plist = list(itertools.chain(*params))
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        for i, p in enumerate(plist):
+            if i % 2 == 0:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+    te.requires_grad_(False)                                             # :704
+    te.requires_grad_(True)                                              # :717 (continue_inversion)
+    table = te.get_input_embeddings().weight
+    for name, p in te.named_parameters():                                # :718-724: everything but the token table frozen again
+        if p is not table:
+            p.requires_grad = False
+    tensors = {"lora.init": orc.flat_params(plist).clone(), "table.init": table.detach().clone()}
+    tensors.update({f"te.{n}": p.detach().clone() for n, p in te.named_parameters() if p is not table})
+    opt = torch.optim.AdamW([{"params": plist, "lr": 1e-3}, {"params": te.get_input_embeddings().parameters(), "lr": 5e-3}],
+                            weight_decay=1e-3)                           # :726-738 (weight_decay_lora)
+    acp = orc.ddpm_alphas_cumprod()
+    losses, all_ids = [], []
+    for step in range(steps):
+        latents, noise, t, _ = orc.synthetic_batch(step, batch, 8, ctx_len, 32, t_max=int(1000 * 0.8))   # :190-195, :444
+        ids = orc.synthetic_token_ids(step, batch, ctx_len, vocab)
+        all_ids.append(ids)
+        opt.zero_grad()                                                  # :436
+        noisy = orc.add_noise(latents, noise, t, acp)
+        ehs = te(ids)[0]                                                 # :199-206
+        pred = unet(noisy, t, ehs).sample
+        target = orc.get_velocity(latents, noise, t, acp)                # :217-218
+        loss = F.mse_loss(pred.float(), target.float(), reduction="mean")  # :247
+        loss.backward()                                                  # :447
+        torch.nn.utils.clip_grad_norm_(itertools.chain(unet.parameters(), te.parameters()), 1.0)  # :448-450
+        opt.step()                                                       # :451
+        losses.append(loss.item())
+    tensors["lora.final"] = orc.flat_params(plist).clone()
+    tensors["table.final"] = table.detach().clone()
+    tensors["losses"] = torch.tensor(losses)
+    tensors["ids"] = torch.stack(all_ids)
+    meta = {"cfg": json.dumps({"vocab": vocab, "ctx_len": ctx_len, "steps": steps, "batch": batch, "latent_hw": 8,
+                               "hidden": 32, "intermediate": 64, "layers": 2, "heads": 2, "lr_unet": 1e-3, "lr_embed": 5e-3,
+                               "weight_decay": 1e-3, "unet_seed": 3, "warm_seed": 11, "warm_std": 0.02, "t_multiplier": 0.8,
+                               "v_prediction": True})}
+    save_file({k: v.contiguous() for k, v in tensors.items()}, os.path.join(OUT, "pti_trajectory.safetensors"), meta)
+
+
 def main():
     import tempfile
 
@@ -287,6 +348,7 @@ def main():
     with tempfile.TemporaryDirectory() as d:
         gen_finder_and_formats(ref, d)
     gen_trajectory(ref)
+    gen_pti_trajectory(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -43,6 +43,11 @@ def golden_trajectory():
 
 
 @pytest.fixture(scope="session")
+def golden_pti():
+    return _load("pti_trajectory.safetensors")
+
+
+@pytest.fixture(scope="session")
 def golden_structure():
     with open(os.path.join(GOLDEN, "structure.json")) as f:
         return json.load(f)

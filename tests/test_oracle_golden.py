@@ -149,3 +149,50 @@ def test_philox_known_answers_and_statistics():
     assert t.min() >= 0 and t.max() < 1000
     eps2, t2 = philox.step_randomness(8, 4 * 64 * 64, 1000, 1234, 8)
     assert not np.array_equal(t, t2) and abs(float((eps * eps2).mean())) < 0.01  # steps are independent streams
+
+
+def build_pti_models(t, cfg, device="cpu", dtype=torch.float32):
+    """The tiny UNet + tiny CLIP text encoder of tests/golden/pti_trajectory.safetensors with the fixture's frozen weights."""
+    from harness.unet import UNet2DConditionModel, tiny_config
+    from transformers import CLIPTextConfig, CLIPTextModel
+
+    torch.manual_seed(cfg["unet_seed"])
+    unet = UNet2DConditionModel(tiny_config(32, 32, 2))
+    unet.requires_grad_(False)
+    te = CLIPTextModel(CLIPTextConfig(hidden_size=cfg["hidden"], intermediate_size=cfg["intermediate"],
+                                      num_hidden_layers=cfg["layers"], num_attention_heads=cfg["heads"], vocab_size=cfg["vocab"],
+                                      max_position_embeddings=cfg["ctx_len"], bos_token_id=1, eos_token_id=2, pad_token_id=0))
+    with torch.no_grad():
+        for n, p in te.named_parameters():
+            p.copy_(t["table.init"] if n.endswith("token_embedding.weight") else t[f"te.{n}"])
+    return unet.to(device).to(dtype), te.to(device).to(dtype)
+
+
+def test_pti_tuning_trajectory_with_trainable_token_embeddings(golden_pti, relerr):
+    """BASELINE config 5's second half: the oracle's restatement of cli_lora_pti.py's tuning step with continue_inversion
+    (LoRA factors + the token table in one AdamW, clip over both, draw below 800, v-prediction) against the trajectory
+    the reference's own LoRA modules + torch.optim.AdamW produced (oracle/make_golden.py::gen_pti_trajectory)."""
+    t, meta = golden_pti
+    cfg = json.loads(meta["cfg"])
+    unet, te = build_pti_models(t, cfg)
+    params, _ = orc.inject(unet, r=4)
+    with torch.no_grad():
+        for p, v in zip(params, torch.split(t["lora.init"], [q.numel() for q in params])):
+            p.copy_(v.view(p.shape))
+    table = orc.freeze_all_but_token_embeddings(te)
+    assert [n for n, p in te.named_parameters() if p.requires_grad] == ["embeddings.token_embedding.weight"] or \
+        [n for n, p in te.named_parameters() if p.requires_grad] == ["text_model.embeddings.token_embedding.weight"]
+    for s in range(cfg["steps"]):  # the fixture's ids are what the generator yields
+        assert torch.equal(orc.synthetic_token_ids(s, cfg["batch"], cfg["ctx_len"], cfg["vocab"]), t["ids"][s])
+    losses = orc.pti_tuning_steps(unet, te, params, cfg["steps"], cfg["batch"], cfg["latent_hw"], cfg["ctx_len"], cfg["vocab"],
+                                  lr_unet=cfg["lr_unet"], lr_embed=cfg["lr_embed"], weight_decay=cfg["weight_decay"],
+                                  v_prediction=cfg["v_prediction"], t_multiplier=cfg["t_multiplier"])
+    assert relerr(torch.tensor(losses), t["losses"]) < 1e-5
+    assert relerr(orc.flat_params(params) - t["lora.init"], t["lora.final"] - t["lora.init"]) < 1e-3
+    assert relerr(orc.flat_params(params), t["lora.final"]) < 2e-5
+    assert relerr(table.detach() - t["table.init"], t["table.final"] - t["table.init"]) < 1e-3
+    # rows of tokens that never occurred only decay (AdamW's decoupled weight decay touches every row, every step)
+    unused = torch.ones(cfg["vocab"], dtype=torch.bool)
+    unused[t["ids"].reshape(-1)] = False
+    decay = (1 - cfg["lr_embed"] * cfg["weight_decay"]) ** cfg["steps"]
+    assert unused.any() and relerr(table.detach()[unused], t["table.init"][unused] * decay) < 1e-6
