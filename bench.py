@@ -123,9 +123,14 @@ CONFIGS = {
     4: dict(tag="cfg-4", unet="sd15", rank=4, batch=4, latent=64, ctx_len=77, ctx_dim=768, prior=True, text_encoder=False,
             v_prediction=False, what="SD1.5 Dreambooth LoRA rank={rank} with prior preservation, {batch} instance + {batch} "
                                      "class rows per GPU (global batch 32 = 4 x 8 GPUs)"),
+    # cli_lora_pti.py's tuning phase as it runs by default (continue_inversion=True, :528): UNet LoRA + the text encoder's
+    # token-embedding table in one AdamW (:706-738, weight_decay_lora 1e-3), the encoder run inside the step (:199-206),
+    # timesteps below int(1000·0.8) (:444), v-prediction (SD2.1-768)
     5: dict(tag="cfg-5", unet="sd21-768", rank=16, batch=1, latent=96, ctx_len=77, ctx_dim=1024, prior=False,
-            text_encoder=False, v_prediction=True, what="SD2.1-768 UNet LoRA rank={rank} (cli_lora_pti tuning phase), "
-                                                        "v-prediction, batch={batch}/GPU"),
+            text_encoder="openclip-h-ti", v_prediction=True, t_multiplier=0.8, weight_decay=1e-3,
+            what="SD2.1-768 PTI tuning step (cli_lora_pti perform_tuning, continue_inversion): UNet LoRA rank={rank} + the "
+                 "trainable token-embedding table (49408x1024, 'extended-latent TI') of an OpenCLIP-H-shaped text encoder run "
+                 "inside the step, attn2 to_k/to_v with dX, t < 800, v-prediction, batch={batch}/GPU"),
 }
 
 
@@ -155,13 +160,24 @@ def build_model(device, dtype, rank_r):  # (tools/ use this name)
     return build_unet(device, dtype, rank_r)
 
 
-def build_text_encoder(device, dtype, rank_r):
-    """CLIP-L-shaped text encoder (hidden 768, 12 layers, 12 heads, MLP 3072, 77 positions — the SD1.5 text encoder's
-    config), random init, LoRA on its CLIPAttention projections (lora.py:54, train_lora_dreambooth.py:608-621)."""
+def build_text_encoder(device, dtype, rank_r, kind=True):
+    """kind True / "clip-l-lora": CLIP-L-shaped text encoder (hidden 768, 12 layers, 12 heads, MLP 3072, 77 positions — the
+    SD1.5 text encoder's config), random init, LoRA on its CLIPAttention projections (lora.py:54,
+    train_lora_dreambooth.py:608-621).  "openclip-h-ti": OpenCLIP-H-shaped (hidden 1024, 23 layers, 16 heads, MLP 4096 — the
+    SD2.1 text encoder's config), frozen except its token-embedding table (cli_lora_pti.py:704-722, continue_inversion)."""
     import diffusion_finetuning_amd as dfa
     from transformers import CLIPTextConfig, CLIPTextModel
 
     torch.manual_seed(2)
+    if kind == "openclip-h-ti":
+        cfg = CLIPTextConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=23, num_attention_heads=16,
+                             vocab_size=49408, max_position_embeddings=77, bos_token_id=49406, eos_token_id=49407,
+                             pad_token_id=0, hidden_act="gelu")
+        te = CLIPTextModel(cfg)
+        te.requires_grad_(False)
+        te = te.to(device).to(dtype)
+        te.get_input_embeddings().weight.requires_grad_(True)  # the one trainable tensor of the encoder (:708-722)
+        return te
     cfg = CLIPTextConfig(hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
                          vocab_size=49408, max_position_embeddings=77, bos_token_id=49406, eos_token_id=49407, pad_token_id=1)
     te = CLIPTextModel(cfg)
@@ -188,7 +204,7 @@ def synthetic_steps(n_steps, batch, latent, rank, world, device, ctx_len=77, ctx
         noise = torch.randn(rows, 4, latent, latent, generator=g)
         t = torch.randint(0, 1000, (rows,), generator=g)
         tok = torch.randint(2, 49000, (world * rows, ctx_len), generator=g)
-        tok[:, 0], tok[:, -1] = 49406, 49407
+        tok[:, 0], tok[:, 24:] = 49406, 49407  # caption-shaped: bos, 23 words, eos repeated to the end (tokenizer padding)
         sl = slice(rank * rows, (rank + 1) * rows)
         cond = tok[sl].to(device) if ids else ctx[sl].to(device)
         out.append((lat[sl].to(device), noise.to(device), t.to(device), cond))
@@ -311,13 +327,14 @@ def run_workload(args, cfg_id, rank, world, device, dist, profile=True):
         cfg["latent"] = args.latent if args.latent is not None else cfg["latent"]
     dtype = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[args.dtype]
     unet = build_unet(device, dtype, cfg["rank"], cfg["unet"])
-    te = build_text_encoder(device, dtype, cfg["rank"]) if cfg["text_encoder"] else None
+    te = build_text_encoder(device, dtype, cfg["rank"], cfg["text_encoder"]) if cfg["text_encoder"] else None
     # forward+backward(+factor gradients) of a step are recorded once into a hipGraph (during the priming step) and
     # replayed; the RCCL exchange and the optimizer are launched from the host every step (trainer.py)
     # (the gloo rehearsal backend stages the slab through the host; with a recorded graph alive in two processes on one
     #  device that path degrades to seconds per step — before and after the recording — so it stays host-launched)
     use_graph = not args.no_graph and (world == 1 or args.backend == "nccl")
-    trainer = LoraTrainer(unet, te, lr=1e-4, lr_text=5e-5, capture_graph=use_graph, v_prediction=cfg["v_prediction"])
+    trainer = LoraTrainer(unet, te, lr=1e-4, lr_text=5e-5, lr_embed=5e-4, weight_decay=cfg.get("weight_decay", 1e-2),
+                          capture_graph=use_graph, v_prediction=cfg["v_prediction"])
     rows_per_image = 2 if cfg["prior"] else 1
     data = synthetic_steps(args.warmup + args.steps, cfg["batch"], cfg["latent"], rank, world, device, cfg["ctx_len"],
                            cfg["ctx_dim"], rows_per_image, ids=te is not None)
@@ -337,7 +354,7 @@ def run_workload(args, cfg_id, rank, world, device, dist, profile=True):
         # here — on the device, in the prologue kernel (Philox4x32-10 keyed by (seed, optimizer step), rank-invariant);
         # --host-noise feeds the pre-drawn tensors of synthetic_steps instead
         lat, noise, t, cond = data[i]
-        kw = dict(with_prior_preservation=cfg["prior"], mask=mask)
+        kw = dict(with_prior_preservation=cfg["prior"], mask=mask, t_multiplier=cfg.get("t_multiplier", 1.0))
         kw["input_ids" if te is not None else "encoder_hidden_states"] = cond
         if args.host_noise:
             return trainer.step(lat, noise, t, **kw)

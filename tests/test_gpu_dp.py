@@ -166,3 +166,71 @@ def test_two_ranks_back_the_loss_scale_off_at_the_same_step():
     assert s0 == s1, (s0, s1)                                   # the same scale at every step on both ranks
     assert s0 == [256.0] * 4 + [128.0] * 4, s0                  # step 2 overflowed → applied at the start of step 2 + LAG
     assert (p0 == p1).all()                                     # and the replicas stayed bit-identical
+
+
+def _run_pti(rank, world, port, batch, out):
+    """The PTI tuning step (trainable token table, cli_lora_pti.py:706-722) under data parallelism: every rank runs the text
+    encoder on ITS captions; the table gradient is exchanged as (ids, gradient rows) — an all-gather in rank order followed by
+    the ordered per-token sum — not as a 200-MB dense all-reduce."""
+    import itertools
+    import json
+
+    import diffusion_finetuning_amd as dfa
+    from diffusion_finetuning_amd import trainer as tr
+    from diffusion_finetuning_amd.attention import set_use_memory_efficient_attention_xformers
+    from oracle import lora_oracle as orc
+    from tests.conftest import _load
+    from tests.test_oracle_golden import build_pti_models
+
+    torch.set_num_threads(2)
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    t, meta = _load("pti_trajectory.safetensors")
+    cfg = json.loads(meta["cfg"])
+    unet, te = build_pti_models(t, cfg, dev, torch.float32)
+    params, _ = dfa.inject_trainable_lora(unet, r=4)
+    plist = list(itertools.chain(*params))
+    with torch.no_grad():
+        for p, v in zip(plist, torch.split(t["lora.init"], [q.numel() for q in plist])):
+            p.copy_(v.view(p.shape).to(dev))
+    set_use_memory_efficient_attention_xformers(unet, True)
+    orc.freeze_all_but_token_embeddings(te)
+    trainer = tr.LoraTrainer(unet, te, lr=1e-3, lr_embed=5e-3, weight_decay=1e-3, v_prediction=True)
+    for step in range(3):
+        latents, noise, ts, _ = orc.synthetic_batch(step, batch * world, 8, cfg["ctx_len"], cfg["hidden"], t_max=800)
+        ids = orc.synthetic_token_ids(step, batch * world, cfg["ctx_len"], cfg["vocab"])
+        sl = slice(rank * batch, (rank + 1) * batch)
+        trainer.step(latents[sl].to(dev), noise[sl].to(dev), ts[sl].to(dev), input_ids=ids[sl].to(dev))
+    a, b = trainer.token_table.range
+    state = torch.cat([trainer.slab.params[: trainer.slab.numel], trainer.slab.params[a:b]]).cpu()
+    if world > 1:
+        gathered = [torch.zeros_like(state) for _ in range(world)]
+        dist.all_gather(gathered, state)
+        assert all(torch.equal(gathered[0], g_) for g_ in gathered)  # replicas — token table included — stay BIT-identical
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        out.put((state.numpy().copy(), trainer.slab.numel))
+
+
+def test_two_ranks_train_the_token_table_like_one_rank_with_double_batch():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run_pti, args=(r, 2, port, 1, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    two, n = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    single = ctx.Process(target=_run_pti, args=(0, 1, port, 2, q))
+    single.start()
+    one, _ = q.get(timeout=300)
+    single.join(timeout=300)
+    assert single.exitcode == 0
+    two, one = torch.from_numpy(two), torch.from_numpy(one)
+    assert ((two[:n] - one[:n]).norm() / one[:n].norm()).item() < 1e-4
+    assert ((two[n:] - one[n:]).norm() / one[n:].norm()).item() < 1e-4

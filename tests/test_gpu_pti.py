@@ -1,0 +1,213 @@
+"""BASELINE config 5's second half — cli_lora_pti.py's tuning phase with continue_inversion (the default, :528): the token
+embedding table of the text encoder trains next to the UNet's LoRA factors (:706-722), the step runs the text encoder itself
+(:199-206), every attn2 to_k/to_v therefore produces a dX into the context, timesteps are drawn below int(1000·0.8) (:444),
+v-prediction target (:217-218).  Checked through the C-ABI against float64 math, against the trajectory the reference's own
+modules produced (tests/golden/pti_trajectory.safetensors) and, at full SD2.1-768 size, against the CPU oracle."""
+import itertools
+import json
+
+import pytest
+import torch
+
+import diffusion_finetuning_amd as dfa
+from diffusion_finetuning_amd import _native as nat
+from diffusion_finetuning_amd import trainer as tr
+from diffusion_finetuning_amd.attention import set_use_hip_geglu, set_use_memory_efficient_attention_xformers
+from oracle import lora_oracle as orc
+from tests.test_oracle_golden import build_pti_models
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_token_rows_gather_and_ordered_row_sum(dtype):
+    """embed_rows_fwd = table[ids] cast; embed_rows_bwd = per-token sum of the gradient rows in position order — against
+    float64 index_add (the sum of ≤ 60 rows of 16-bit values is exact in fp32 up to rounding: 1e-6), rows of absent tokens
+    untouched, accumulate on top of an earlier pass, bit-reproducible run to run."""
+    g = torch.Generator().manual_seed(3)
+    V, D, n = 500, 1024, 2 * 77
+    table = torch.randn(V, D, generator=g).to(DEV)
+    ids = torch.randint(0, V, (2, 77), generator=g)
+    ids[:, 40:] = 7            # padding: one token in 74 positions
+    ids[0, 3] = ids[1, 5] = 11  # a token that occurs in both rows
+    ids = ids.to(DEV)
+    rows = nat.embed_rows_fwd(table, ids, dtype)
+    assert rows.shape == (2, 77, D) and rows.dtype == dtype
+    assert torch.equal(rows, table[ids].to(dtype))
+    d = torch.randn(n, D, generator=g).to(dtype).to(DEV)
+    grad = torch.full((V, D), 3.0, device=DEV)
+    nat.embed_rows_bwd(d, ids.reshape(-1), grad)
+    want = torch.zeros(V, D, dtype=torch.float64).index_add_(0, ids.reshape(-1).cpu(), d.double().cpu())
+    hit = torch.zeros(V, dtype=torch.bool)
+    hit[ids.reshape(-1).cpu()] = True
+    assert (grad[hit.to(DEV)].double().cpu() - want[hit]).abs().max() < 2e-5 * want[hit].abs().max()
+    assert torch.equal(grad[(~hit).to(DEV)], torch.full_like(grad[(~hit).to(DEV)], 3.0))  # absent tokens: untouched
+    again = torch.full((V, D), 3.0, device=DEV)
+    nat.embed_rows_bwd(d, ids.reshape(-1), again)
+    assert torch.equal(again, grad)  # one owner per token, fixed order
+    nat.embed_rows_bwd(d, ids.reshape(-1), again, accumulate=True)
+    assert (again[hit.to(DEV)].double().cpu() - 2 * want[hit]).abs().max() < 4e-5 * want[hit].abs().max()
+
+
+def _tiny_trainer(t, cfg, dtype, graph=False, grouped=True, hook=True):
+    unet, te = build_pti_models(t, cfg, DEV, dtype)
+    params, _ = dfa.inject_trainable_lora(unet, r=4)
+    plist = list(itertools.chain(*params))
+    with torch.no_grad():
+        for p, v in zip(plist, torch.split(t["lora.init"], [q.numel() for q in plist])):
+            p.copy_(v.view(p.shape).to(DEV))
+    if hook:
+        set_use_memory_efficient_attention_xformers(unet, True)
+    orc.freeze_all_but_token_embeddings(te)  # what cli_lora_pti.py:704-722 leaves trainable
+    trainer = tr.LoraTrainer(unet, te, lr=cfg["lr_unet"], lr_embed=cfg["lr_embed"], weight_decay=cfg["weight_decay"],
+                             v_prediction=cfg["v_prediction"], capture_graph=graph, group_projections=grouped)
+    assert trainer.token_table is not None and trainer.trains_text_encoder
+    return trainer, unet, te
+
+
+def _run_tiny(t, cfg, trainer, steps=None):
+    losses = []
+    for s in range(steps or cfg["steps"]):
+        lat, noise, ts, _ = orc.synthetic_batch(s, cfg["batch"], cfg["latent_hw"], cfg["ctx_len"], cfg["hidden"],
+                                                t_max=int(1000 * cfg["t_multiplier"]))
+        losses.append(trainer.step(lat.to(DEV), noise.to(DEV), ts.to(DEV), input_ids=t["ids"][s].to(DEV)))
+    return torch.stack(losses).reshape(-1).cpu()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_pti_tuning_trajectory_matches_the_reference_produced_one(golden_pti, relerr, graph):
+    """fp32, 8 steps: LoRA factors AND token table within 1e-3 of the trajectory produced by the reference's LoRA modules +
+    torch.optim.AdamW (two param groups, one weight decay) + clip_grad_norm_ over both models — host-launched and as a
+    recorded step (text encoder forward/backward, the gather and the stashed gradient rows inside the recording)."""
+    t, meta = golden_pti
+    cfg = json.loads(meta["cfg"])
+    trainer, unet, te = _tiny_trainer(t, cfg, torch.float32, graph=graph)
+    losses = _run_tiny(t, cfg, trainer)
+    if graph:
+        assert trainer._graph is not None
+    table = te.get_input_embeddings().weight.detach().cpu()
+    assert relerr(losses, t["losses"]) < 1e-3, relerr(losses, t["losses"])
+    assert relerr(tr.flat_lora_state(unet).cpu(), t["lora.final"]) < 1e-3
+    assert relerr(tr.flat_lora_state(unet).cpu() - t["lora.init"], t["lora.final"] - t["lora.init"]) < 2e-2
+    assert relerr(table, t["table.final"]) < 1e-3
+    assert relerr(table - t["table.init"], t["table.final"] - t["table.init"]) < 2e-2, \
+        relerr(table - t["table.init"], t["table.final"] - t["table.init"])
+    # the Parameter the caller holds IS the trained table (save_all reads it: cli_lora_pti.py:461-470)
+    assert te.get_input_embeddings().weight.data_ptr() == trainer.slab.params[trainer.token_table.range[0]:].data_ptr()
+
+
+def test_grouped_context_projection_produces_the_context_gradient(golden_pti, relerr):
+    """With a context that carries a gradient the attn2 to_k/to_v of all blocks still run as ONE forward launch, and their dX
+    comes from one launch over the concatenated contraction (groups._CtxProjFn.backward) — the f16 trajectory, token table
+    included, follows the per-layer one (32 dX launches + 31 accumulations) and the fp32 oracle's."""
+    t, meta = golden_pti
+    cfg = json.loads(meta["cfg"])
+    tg, ug, teg = _tiny_trainer(t, cfg, torch.float16)
+    lg = _run_tiny(t, cfg, tg, 4)
+    assert tg.slab.ctx_groups and tg.slab.ctx_groups[0]._pass is not None and tg.slab.ctx_groups[0]._pass.consumers > 0
+    tu, uu, teu = _tiny_trainer(t, cfg, torch.float16, grouped=False)
+    lu = _run_tiny(t, cfg, tu, 4)
+    assert not tu.slab.ctx_groups
+    tab_g, tab_u = teg.get_input_embeddings().weight.detach().float().cpu(), teu.get_input_embeddings().weight.detach().float().cpu()
+    assert relerr(lg, lu) < 2e-3, relerr(lg, lu)
+    assert relerr(tr.flat_lora_state(ug), tr.flat_lora_state(uu)) < 2e-3
+    assert relerr(tab_g - t["table.init"], tab_u - t["table.init"]) < 5e-2, relerr(tab_g - t["table.init"], tab_u - t["table.init"])
+    assert relerr(lg, t["losses"][:4]) < 5e-3
+
+
+def test_full_size_cfg5_pti_step_with_token_embeddings_vs_cpu_oracle(relerr):
+    """BASELINE config 5 as cli_lora_pti.py runs it, at full size: SD2.1-768-shaped UNet (LoRA r = 16, 96×96 latents, batch 1)
+    + an OpenCLIP-H-shaped text encoder (hidden 1024, 23 layers, 16 heads, MLP 4096, vocabulary 49408, 77 positions; random
+    init) whose token table trains; the step runs the encoder from token ids, attn2 to_k/to_v produce dX at ctx 1024 / r = 16,
+    timestep drawn below 800, v-prediction.  ONE f16 step against the fp32 CPU oracle (oracle.pti_tuning_steps): loss, the
+    direction of the LoRA gradient slab and of the table-gradient rows of the tokens that occurred, the update of both."""
+    import bench
+    from harness.unet import UNet2DConditionModel, sd21_768_config
+    from transformers import CLIPTextConfig, CLIPTextModel
+
+    torch.set_num_threads(bench.usable_cpus())
+    vocab, L = 49408, 77
+    ccfg = CLIPTextConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=23, num_attention_heads=16,
+                          vocab_size=vocab, max_position_embeddings=L, bos_token_id=49406, eos_token_id=49407, pad_token_id=0,
+                          hidden_act="gelu")
+
+    def make():
+        torch.manual_seed(0)
+        u = UNet2DConditionModel(sd21_768_config())
+        u.requires_grad_(False)
+        torch.manual_seed(2)
+        e = CLIPTextModel(ccfg)
+        e.requires_grad_(False)
+        return u, e
+
+    lr_u, lr_e, wd = 1e-4, 5e-4, 1e-3   # cli_lora_pti.py:525-537 defaults (lr_unet, learning_rate_ti, weight_decay_lora)
+    ref_unet, ref_te = make()
+    ref_params, _ = orc.inject(ref_unet, r=16)
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for i, p in enumerate(ref_params):
+            if i % 2 == 0:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.01)
+    init_state = orc.flat_params(ref_params).clone()
+    u_state = {k: v.clone() for k, v in ref_unet.state_dict().items() if "lora_" not in k}
+    t_state = {k: v.clone() for k, v in ref_te.state_dict().items()}
+    table = orc.freeze_all_but_token_embeddings(ref_te)
+    table_init = table.detach().clone()
+    ids = orc.synthetic_token_ids(0, 1, L, vocab, bos=49406, eos=49407)
+    ref_losses = orc.pti_tuning_steps(ref_unet, ref_te, ref_params, 1, 1, 96, L, vocab, lr_unet=lr_u, lr_embed=lr_e,
+                                      weight_decay=wd, bos=49406, eos=49407)
+    ref_grad = torch.cat([p.grad.reshape(-1) for p in ref_params])
+    ref_tgrad = table.grad.clone()
+    want, want_table = orc.flat_params(ref_params), table.detach().clone()
+    del ref_unet, ref_te
+
+    unet, te = make()
+    unet.load_state_dict({k.replace(".linear.", "."): v for k, v in u_state.items()})
+    te.load_state_dict(t_state)
+    unet, te = unet.half().to(DEV), te.half().to(DEV)
+    params, _ = dfa.inject_trainable_lora(unet, r=16)
+    plist = list(itertools.chain(*params))
+    with torch.no_grad():
+        for p, rp in zip(plist, torch.split(init_state, [q.numel() for q in plist])):
+            p.copy_(rp.view(p.shape).to(DEV))
+        te.get_input_embeddings().weight.data = table_init.to(DEV)  # the fp32 master (the module copy above was rounded to f16)
+    set_use_memory_efficient_attention_xformers(unet, True)
+    set_use_hip_geglu(unet, True)
+    orc.freeze_all_but_token_embeddings(te)
+    trainer = tr.LoraTrainer(unet, te, lr=lr_u, lr_embed=lr_e, weight_decay=wd, v_prediction=True)
+    assert trainer.token_table is not None and trainer.slab.ctx_groups[0].G == 32 and len(trainer.slab.qkv_groups) == 16
+    lat, noise, ts, _ = orc.synthetic_batch(0, 1, 96, L, 1024, t_max=800)
+    loss = trainer.step(lat.to(DEV), noise.to(DEV), ts.to(DEV), input_ids=ids.to(DEV)).item()
+    assert not trainer.opt.overflowed()
+    assert trainer.slab.ctx_groups[0]._pass is not None  # the grouped projection ran — with a context that wants a gradient
+    assert abs(loss - ref_losses[0]) / abs(ref_losses[0]) < 3e-3, (loss, ref_losses[0])
+    # LoRA slab: direction of the gradient (whole slab, worst layer) and the update
+    grad = trainer.slab.grads[: trainer.slab.numel].cpu()
+    gn, rn = grad / grad.norm(), ref_grad / ref_grad.norm()
+    worst = max(relerr(gn[o:o + n], rn[o:o + n]) for o, n in trainer.slab.offsets)
+    print(f"cfg-5 PTI step: loss {loss:.5f} vs {ref_losses[0]:.5f}; LoRA grad direction err {relerr(gn, rn):.2e} (worst layer {worst:.2e})")
+    assert relerr(gn, rn) < 1.5e-2 and worst < 8e-2, (relerr(gn, rn), worst)
+    got = tr.flat_lora_state(unet).cpu()
+    agree = (((got - init_state) * (want - init_state)) > 0).float().mean().item()
+    assert agree > 0.96, agree
+    # token table: gradient rows exist exactly for the tokens that occurred, their direction matches the oracle's
+    a, b = trainer.token_table.range
+    tgrad = trainer.slab.grads[a:b].view(vocab, 1024).cpu()
+    used = torch.zeros(vocab, dtype=torch.bool)
+    used[ids.reshape(-1)] = True
+    assert float(tgrad[~used].abs().max()) == 0.0 and float(ref_tgrad[~used].abs().max()) == 0.0
+    # (compare like with like: the oracle's rows are clipped with the global coefficient, ours are not yet scaled → directions)
+    tn, trn = tgrad[used] / tgrad[used].norm(), ref_tgrad[used] / ref_tgrad[used].norm()
+    print(f"  table-gradient rows ({int(used.sum())} tokens): direction err {relerr(tn, trn):.2e}")
+    assert relerr(tn, trn) < 3e-2, relerr(tn, trn)
+    # relative size of the two gradient blocks (what the shared clip norm sees)
+    ratio = (tgrad.norm() / grad.norm()).item() / (ref_tgrad.norm() / ref_grad.norm()).item()
+    assert abs(ratio - 1) < 2e-2, ratio
+    got_table = te.get_input_embeddings().weight.detach().float().cpu()
+    upd, wupd = got_table[used] - table_init[used], want_table[used] - table_init[used]
+    t_agree = ((upd * wupd) > 0).float().mean().item()
+    print(f"  update sign agreement: LoRA {agree:.4f}, table rows {t_agree:.4f}")
+    assert t_agree > 0.95, t_agree
+    # rows of absent tokens: decoupled weight decay only, bit-for-bit AdamW semantics on a zero gradient
+    assert relerr(got_table[~used][:2000], want_table[~used][:2000]) < 1e-6
