@@ -41,6 +41,8 @@ def parse():
                     help="time ONLY the unchanged reference trainer loop (no LoraTrainer): what extra.drop_in reports")
     ap.add_argument("--mask", action="store_true", help="masked loss (cli_lora_pti.py:222-247) on a random binary mask")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32"])
+    ap.add_argument("--channels-last", action="store_true",
+                    help="caller-side experiment: run the UNet's convolution trunk in channels-last (NHWC) memory format")
     ap.add_argument("--no-prof", action="store_true", help="do not attach kernel events in the timed region")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel from the host each step instead of replaying the recorded hipGraph")
@@ -211,6 +213,7 @@ def synthetic_steps(n_steps, batch, latent, rank, world, device, ctx_len=77, ctx
     return out
 
 
+
 def measured_traffic(kernel_name, dtype):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/*pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE
@@ -327,6 +330,8 @@ def run_workload(args, cfg_id, rank, world, device, dist, profile=True):
         cfg["latent"] = args.latent if args.latent is not None else cfg["latent"]
     dtype = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[args.dtype]
     unet = build_unet(device, dtype, cfg["rank"], cfg["unet"])
+    if args.channels_last:
+        unet = unet.to(memory_format=torch.channels_last)
     te = build_text_encoder(device, dtype, cfg["rank"], cfg["text_encoder"]) if cfg["text_encoder"] else None
     # forward+backward(+factor gradients) of a step are recorded once into a hipGraph (during the priming step) and
     # replayed; the RCCL exchange and the optimizer are launched from the host every step (trainer.py)
@@ -441,6 +446,18 @@ def run_workload(args, cfg_id, rank, world, device, dist, profile=True):
         losses.append(run_step(i))
     barrier()
     elapsed = time.perf_counter() - t0
+    # What a step does OUTSIDE the recording, per rank: [RCCL all-reduce of the slab] → clip norm + AdamW → re-pack of the
+    # compute-dtype factors (+ the token-table row sum of config 5).  Timed with events in a few extra replayed steps after the
+    # timed region (not part of `value`); on one GPU the exchange is empty, so this is the floor the 8-GPU step adds its
+    # all-reduce to.
+    tail_ms = None
+    if trainer.capture_graph and trainer._graph is not None:
+        trainer.tail_events = []
+        for i in range(args.warmup, args.warmup + min(5, args.steps)):
+            run_step(i)
+        torch.cuda.synchronize()
+        tail_ms = sorted(a.elapsed_time(b) for a, b in trainer.tail_events)[len(trainer.tail_events) // 2]
+        trainer.tail_events = None
     # Roofline pass: the SAME K steps again with start/stop events attached to every hot-path dispatch.  It is a
     # second pass because the events serialise consecutive dispatches (≈4 % on the step), which must not leak into
     # `value`; all ranks run it so that the collectives stay matched.
@@ -468,7 +485,7 @@ def run_workload(args, cfg_id, rank, world, device, dist, profile=True):
         log(f"[{cfg['tag']}] timed region done: {1e3 * elapsed / args.steps:.2f} ms/step; losses: " +
             " ".join(f"{float(l.item()):.4f}" for l in losses))
     res = {"cfg": cfg, "elapsed": elapsed, "elapsed_prof": elapsed_prof, "prof": prof, "graph_used": bool(graph_used),
-           "launch_trial": launch_trial, "survey": trainer.slab.survey_work(2 if args.dtype != "f32" else 4),
+           "tail_ms": tail_ms, "launch_trial": launch_trial, "survey": trainer.slab.survey_work(2 if args.dtype != "f32" else 4),
            "final_loss": final_loss, "overflow": trainer.opt.overflowed(), "lora_params": trainer.slab.numel,
            "rows_per_image": rows_per_image}
     del trainer, unet, te, data
@@ -614,6 +631,8 @@ def main():
                        "hipgraph": head["graph_used"], "launch_mode_trial": head["launch_trial"],
                        # world size as the process group itself reports it (a SCALE record can be checked against it)
                        "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
+                       # device time of the step's host-launched tail (exchange + clip/AdamW + re-pack), median of 5 steps
+                       "tail_ms_per_step": head["tail_ms"],
                        "backend": (dist.get_backend() if world > 1 else None),
                        "noise": "pre-drawn on the host" if args.host_noise else
                                 "drawn on the device inside the step (Philox4x32-10 prologue kernel, rank-invariant)"},
@@ -699,7 +718,7 @@ def main():
                      "rows_s": c["batch"] * r["rows_per_image"] * args.steps / r["elapsed"],
                      "ms_per_step": 1e3 * r["elapsed"] / args.steps, "hipgraph": r["graph_used"],
                      "lora_params": r["lora_params"], "final_loss": r["final_loss"], "overflow": r["overflow"],
-                     "launch_mode_trial": r["launch_trial"],
+                     "launch_mode_trial": r["launch_trial"], "tail_ms_per_step": r["tail_ms"],
                      "survey_MB_per_step": (r["survey"]["fwd_bytes"] + r["survey"]["bwd_bytes"]) / 1e6}
                 if r["prof"]:
                     hp = hot_path_summary(r["prof"], args.steps, r["elapsed_prof"])

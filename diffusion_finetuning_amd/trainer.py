@@ -592,6 +592,7 @@ class LoraTrainer:
         self.opt = FusedClipAdamW(self.slab, groups, betas, eps, max_grad_norm)
         self.device = self.slab.params.device
         self.dtype = next(p for p in unet.parameters() if p.dim() == 4).dtype  # conv weight dtype = compute dtype
+        self.tail_events = None  # a list switches on the timing of the host-launched tail of every replayed step
         self.token_table = None
         if train_emb:
             te_dtype = next((p.dtype for n_, p in text_encoder.named_parameters() if p is not emb.weight), torch.float32)
@@ -863,12 +864,18 @@ class LoraTrainer:
         else:
             self._graph_inputs(st, latents, noise, timesteps, ehs, ids, mask, seed)
         st["graph"].replay()
+        tail = self.tail_events
+        if tail is not None:  # (bench.py: device time of the host-launched tail — exchange, clip + AdamW, re-pack)
+            tail.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+            tail[-1][0].record()
         self.exchange.finish()
         if self.token_table is not None:
             self.token_table.collect(self.pg, self.world if self.exchange.active else 1)
         self.opt.step(grad_mul=1.0 / (self.world * self.loss_scale))
         self._watch_overflow()
         self.slab.repack()
+        if tail is not None:
+            tail[-1][1].record()
         return st["loss"].clone()
 
 

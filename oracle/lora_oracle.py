@@ -232,13 +232,20 @@ def synthetic_batch(step: int, batch: int, latent_hw: int, ctx_len: int, ctx_dim
 
 def train_steps(unet, params: List[torch.Tensor], steps: int, batch: int, latent_hw: int, ctx_len: int,
                 ctx_dim: int, lr=1e-4, weight_decay=1e-2, max_grad_norm=1.0, with_prior=False,
-                prior_loss_weight=1.0, v_prediction=False, world: int = 1, first_step: int = 0):
+                prior_loss_weight=1.0, v_prediction=False, world: int = 1, first_step: int = 0,
+                state: Optional[dict] = None):
     """`steps` optimizer steps of the reference loop on CPU.  `world` > 1 emulates synchronous data
     parallelism: each virtual rank takes its own slice of a `world*batch` batch and the gradients are
-    averaged (DDP mean all-reduce, train_lora_dreambooth.py:744-757,877).  Returns the loss history."""
+    averaged (DDP mean all-reduce, train_lora_dreambooth.py:744-757,877).  Returns the loss history.
+    `state`: a dict that carries the optimizer state (Adam moments, step count) from one call to the next, so that a
+    trajectory can be produced in pieces (a test that looks at the gradients of the first step, then continues)."""
     acp = ddpm_alphas_cumprod()
-    m = [torch.zeros_like(p) for p in params]
-    v = [torch.zeros_like(p) for p in params]
+    if state is not None and "m" in state:
+        m, v, done = state["m"], state["v"], state["t"]
+    else:
+        m = [torch.zeros_like(p) for p in params]
+        v = [torch.zeros_like(p) for p in params]
+        done = 0
     losses = []
     for s in range(first_step, first_step + steps):
         latents, noise, t, ctx = synthetic_batch(s, batch * world, latent_hw, ctx_len, ctx_dim)
@@ -257,8 +264,10 @@ def train_steps(unet, params: List[torch.Tensor], steps: int, batch: int, latent
         clip_grad_norm(grads, max_grad_norm)
         for p, g, mm, vv in zip(params, grads, m, v):
             with torch.no_grad():
-                adamw_step(p, g, mm, vv, s - first_step + 1, lr, weight_decay=weight_decay)
+                adamw_step(p, g, mm, vv, done + s - first_step + 1, lr, weight_decay=weight_decay)
         losses.append(sum(step_losses) / world)
+    if state is not None:
+        state.update(m=m, v=v, t=done + steps)
     return losses
 
 

@@ -463,12 +463,22 @@ def _sd15(device, dtype, seed=0):
     return m.to(dtype)
 
 
-@pytest.mark.parametrize("prior", [False, True])
-def test_full_size_fp16_step_vs_fp32_cpu_oracle(relerr, prior):
-    """BASELINE config 2 (batch 4, 64×64 latents, f16, grouped projections + HIP attention cores, exactly what bench.py
-    times) and config 4's per-GPU step (prior preservation: 4 instance + 4 class rows → M = 32768): ONE full-size step
-    each against the fp32 CPU oracle on the same weights and inputs — loss and the LoRA UPDATE (tolerance of the
-    existing cfg-1 check on the update; f16 compute)."""
+def weighted_sign_agreement(update, ref_update, ref_grad):
+    """Share of the reference gradient's L1 mass whose UPDATE has the reference's sign.  Adam's first step moves every element
+    by ≈ lr·sign(g): comparing states says nothing after one step of 1e-4, and an unweighted sign count is dominated by the
+    elements whose gradient is indistinguishable from zero in f16 — this puts the weight where the gradient is."""
+    w = ref_grad.abs().double()
+    return float((w * ((update.double() * ref_update.double()) > 0)).sum() / w.sum())
+
+
+@pytest.mark.parametrize("prior,steps", [(False, 8), (True, 6)])
+def test_full_size_fp16_trajectory_vs_fp32_cpu_oracle(relerr, prior, steps):
+    """BASELINE configs 2 (batch 4) and 4 (prior preservation: 4 instance + 4 class rows per GPU) at full size — SD1.5-shaped
+    UNet, 64×64 latents, f16 compute with every fused path switched on (grouped projections, both attention cores, gated GEGLU
+    epilogues, fused loss, clip + AdamW) — SEVERAL steps against the fp32 CPU oracle loop (train_lora_dreambooth.py:811-888) on
+    the same weights and inputs.  north_star: "output LoRA within 1e-3 of the CPU reference" — after one step of lr 1e-4 an
+    un-updated state would pass that, so the assertions are on what training DID: the loss history, the direction of the
+    first step's gradient slab (what the all-reduce carries), and the accumulated UPDATE (state − init) over the steps."""
     import bench
 
     torch.set_num_threads(bench.usable_cpus())
@@ -482,8 +492,12 @@ def test_full_size_fp16_step_vs_fp32_cpu_oracle(relerr, prior):
                 p.copy_(torch.randn(p.shape, generator=g) * 0.01)
     init_state = orc.flat_params(ref_params).clone()
     state = {k: v.clone() for k, v in ref.state_dict().items() if "lora_" not in k}
-    ref_losses = orc.train_steps(ref, ref_params, 1, batch, 64, 77, 768, lr=1e-4, with_prior=prior)
+    opt_state = {}
+    ref_losses = orc.train_steps(ref, ref_params, 1, batch, 64, 77, 768, lr=1e-4, with_prior=prior, state=opt_state)
     ref_grad = torch.cat([p.grad.reshape(-1) for p in ref_params])  # clipped in place: a global factor, direction kept
+    want1 = orc.flat_params(ref_params).clone()
+    ref_losses += orc.train_steps(ref, ref_params, steps - 1, batch, 64, 77, 768, lr=1e-4, with_prior=prior, first_step=1,
+                                  state=opt_state)
     want = orc.flat_params(ref_params)
     del ref
 
@@ -499,20 +513,31 @@ def test_full_size_fp16_step_vs_fp32_cpu_oracle(relerr, prior):
     set_use_hip_geglu(unet, True)
     trainer = tr.LoraTrainer(unet, lr=1e-4)
     assert len(trainer.slab.qkv_groups) == 16 and trainer.slab.ctx_groups[0].G == 32
-    lat, noise, ts, ctx = orc.synthetic_batch(0, batch, 64, 77, 768)
-    loss = trainer.step(lat.to(DEV), noise.to(DEV), ts.to(DEV), ctx.to(DEV), with_prior_preservation=prior).item()
-    assert not trainer.opt.overflowed()
+    losses = []
+    for step in range(steps):
+        lat, noise, ts, ctx = orc.synthetic_batch(step, batch, 64, 77, 768)
+        losses.append(trainer.step(lat.to(DEV), noise.to(DEV), ts.to(DEV), ctx.to(DEV), with_prior_preservation=prior).item())
+        if step == 0:
+            assert not trainer.opt.overflowed()
+            grad = trainer.slab.grads[: trainer.slab.numel].cpu()
+            got1 = tr.flat_lora_state(unet).cpu()
+    assert not trainer.opt.overflowed() and trainer.opt.applied_steps() == steps
     got = tr.flat_lora_state(unet).cpu()
-    assert abs(loss - ref_losses[0]) / abs(ref_losses[0]) < 2e-3, (loss, ref_losses[0])
-    # the gradient slab (what the all-reduce carries), direction against the oracle's: whole slab and worst layer
-    grad = trainer.slab.grads[: trainer.slab.numel].cpu()
+    # loss history
+    lerr = max(abs(a - b) / abs(b) for a, b in zip(losses, ref_losses))
+    # first step: the gradient slab's direction against the oracle's (whole slab and worst layer) and the update's signs
     gn, rn = grad / grad.norm(), ref_grad / ref_grad.norm()
-    assert relerr(gn, rn) < 1e-2, relerr(gn, rn)
     worst = max(relerr(gn[o:o + n], rn[o:o + n]) for o, n in trainer.slab.offsets)
-    assert worst < 5e-2, worst
-    # one AdamW step moves every element by ≈ ±lr·sign(g): the signs must agree except at gradient zero-crossings
-    agree = (((got - init_state) * (want - init_state)) > 0).float().mean().item()
-    assert agree > 0.97, agree  # f16 compute: elements whose gradient is within ~2 % of the layer's rms may flip
+    wsign = weighted_sign_agreement(got1 - init_state, want1 - init_state, ref_grad)
+    # all steps: the accumulated update
+    uerr = relerr(got - init_state, want - init_state)
+    print(f"cfg-{4 if prior else 2} f16, {steps} steps vs fp32 oracle: max loss err {lerr:.2e}; step-1 gradient direction err "
+          f"{relerr(gn, rn):.2e} (worst layer {worst:.2e}), |g|-weighted update-sign agreement {wsign:.4f}; update err after "
+          f"{steps} steps {uerr:.3e}; state err {relerr(got, want):.2e}")
+    assert lerr < 2e-3, lerr
+    assert relerr(gn, rn) < 1e-2 and worst < 5e-2, (relerr(gn, rn), worst)
+    assert wsign > 0.995, wsign
+    assert uerr < 0.1, uerr
     assert relerr(got, want) < 1e-3
 
 
@@ -521,14 +546,20 @@ def _copy_frozen(ref_state, model):
 
 
 def _check_update(got, want, init, grad, ref_grad, offsets, relerr, loss, ref_loss):
+    """Single-step configs: loss, direction of the gradient slab, and the UPDATE — Adam's first step is ≈ lr·sign(g), so the
+    update is judged by its signs, weighted by |g| (the state itself would pass un-updated: lr 1e-4 on factors of 0.01–0.25)."""
     assert abs(loss - ref_loss) / abs(ref_loss) < 3e-3, (loss, ref_loss)
     gn, rn = grad / grad.norm(), ref_grad / ref_grad.norm()
     assert relerr(gn, rn) < 1.5e-2, relerr(gn, rn)
     worst = max(relerr(gn[o:o + n], rn[o:o + n]) for o, n in offsets)
     assert worst < 8e-2, worst
     agree = (((got - init) * (want - init)) > 0).float().mean().item()
+    wsign = weighted_sign_agreement(got - init, want - init, ref_grad)
+    print(f"single step: loss err {abs(loss - ref_loss) / abs(ref_loss):.2e}, gradient direction err {relerr(gn, rn):.2e} "
+          f"(worst layer {worst:.2e}), update signs agree on {agree:.4f} of the elements / {wsign:.4f} of the gradient mass")
     assert agree > 0.96, agree
-    assert relerr(got, want) < 1e-3
+    assert wsign > 0.99, wsign
+    assert float((got - init).abs().max()) > 0.5e-4  # the step was applied (|Δ| ≈ lr = 1e-4)
 
 
 def test_full_size_cfg5_sd21_768_rank16_v_prediction_step_vs_cpu_oracle(relerr):

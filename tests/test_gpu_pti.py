@@ -97,23 +97,82 @@ def test_pti_tuning_trajectory_matches_the_reference_produced_one(golden_pti, re
     assert te.get_input_embeddings().weight.data_ptr() == trainer.slab.params[trainer.token_table.range[0]:].data_ptr()
 
 
-def test_grouped_context_projection_produces_the_context_gradient(golden_pti, relerr):
+def test_grouped_context_projection_produces_the_context_gradient(relerr):
     """With a context that carries a gradient the attn2 to_k/to_v of all blocks still run as ONE forward launch, and their dX
     comes from one launch over the concatenated contraction (groups._CtxProjFn.backward) — the f16 trajectory, token table
-    included, follows the per-layer one (32 dX launches + 31 accumulations) and the fp32 oracle's."""
-    t, meta = golden_pti
-    cfg = json.loads(meta["cfg"])
-    tg, ug, teg = _tiny_trainer(t, cfg, torch.float16)
-    lg = _run_tiny(t, cfg, tg, 4)
-    assert tg.slab.ctx_groups and tg.slab.ctx_groups[0]._pass is not None and tg.slab.ctx_groups[0]._pass.consumers > 0
-    tu, uu, teu = _tiny_trainer(t, cfg, torch.float16, grouped=False)
-    lu = _run_tiny(t, cfg, tu, 4)
+    included, follows the per-layer one (2·blocks dX launches + their accumulations) and the fp32 CPU oracle's.  (A model
+    whose context width is a multiple of 64: the tiny fixture model's 32-wide context is not groupable.)"""
+    from harness.unet import UNet2DConditionModel, tiny_config
+    from transformers import CLIPTextConfig, CLIPTextModel
+
+    vocab, L, steps, batch = 80, 8, 4, 2
+    ccfg = CLIPTextConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2, vocab_size=vocab,
+                          max_position_embeddings=L, bos_token_id=1, eos_token_id=2, pad_token_id=0)
+
+    def make():
+        torch.manual_seed(3)
+        u = UNet2DConditionModel(tiny_config(64, 64, 2))
+        u.requires_grad_(False)
+        torch.manual_seed(4)
+        e = CLIPTextModel(ccfg)
+        return u, e
+
+    def warm(params):
+        g = torch.Generator().manual_seed(11)
+        with torch.no_grad():
+            for i, p in enumerate(params):
+                if i % 2 == 0:
+                    p.copy_((torch.randn(p.shape, generator=g) * 0.02).to(p.device))
+
+    ref_unet, ref_te = make()
+    ref_params, _ = orc.inject(ref_unet, r=4)
+    warm(ref_params)
+    ref_table = orc.freeze_all_but_token_embeddings(ref_te)
+    table_init = ref_table.detach().clone()
+    ref_losses = orc.pti_tuning_steps(ref_unet, ref_te, ref_params, steps, batch, 8, L, vocab, lr_unet=1e-3, lr_embed=5e-3)
+
+    def train(grouped):
+        unet, te = make()
+        unet, te = unet.to(DEV).half(), te.to(DEV).half()
+        params, _ = dfa.inject_trainable_lora(unet, r=4)
+        warm(list(itertools.chain(*params)))
+        with torch.no_grad():
+            te.get_input_embeddings().weight.data = table_init.to(DEV)  # fp32 master, not the f16-rounded module copy
+        set_use_memory_efficient_attention_xformers(unet, True)
+        orc.freeze_all_but_token_embeddings(te)
+        trainer = tr.LoraTrainer(unet, te, lr=1e-3, lr_embed=5e-3, weight_decay=1e-3, v_prediction=True, group_projections=grouped)
+        losses, g1 = [], None
+        for s_ in range(steps):
+            lat, noise, ts, _ = orc.synthetic_batch(s_, batch, 8, L, 64, t_max=800)
+            ids = orc.synthetic_token_ids(s_, batch, L, vocab)
+            losses.append(trainer.step(lat.to(DEV), noise.to(DEV), ts.to(DEV), input_ids=ids.to(DEV)))
+            if s_ == 0:  # the table gradient of the first step: what the context's dX turned into, before Adam touches it
+                a, b = trainer.token_table.range
+                g1 = trainer.slab.grads[a:b].view(vocab, 64).cpu().clone()
+        return (trainer, tr.flat_lora_state(unet).cpu(), te.get_input_embeddings().weight.detach().float().cpu(),
+                torch.stack(losses).reshape(-1).cpu(), g1)
+
+    tg, lora_g, tab_g, lg, g1_g = train(True)
+    grp = tg.slab.ctx_groups[0]
+    assert grp._pass is not None and grp._pass.consumers == len(grp.modules) == 4  # the group ran, context gradient and all
+    tu, lora_u, tab_u, lu, g1_u = train(False)
     assert not tu.slab.ctx_groups
-    tab_g, tab_u = teg.get_input_embeddings().weight.detach().float().cpu(), teu.get_input_embeddings().weight.detach().float().cpu()
+    # the gradient that went through the grouped dX launch against the per-layer launches (+ accumulations), and against the
+    # oracle's (the oracle's is clipped: compare directions)
+    assert relerr(g1_g, g1_u) < 1e-2, relerr(g1_g, g1_u)
+    ref1_u, ref1_te = make()
+    ref1_params, _ = orc.inject(ref1_u, r=4)
+    warm(ref1_params)
+    ref1_table = orc.freeze_all_but_token_embeddings(ref1_te)
+    orc.pti_tuning_steps(ref1_u, ref1_te, ref1_params, 1, batch, 8, L, vocab, lr_unet=1e-3, lr_embed=5e-3)
+    assert relerr(g1_g / g1_g.norm(), ref1_table.grad / ref1_table.grad.norm()) < 2e-2
     assert relerr(lg, lu) < 2e-3, relerr(lg, lu)
-    assert relerr(tr.flat_lora_state(ug), tr.flat_lora_state(uu)) < 2e-3
-    assert relerr(tab_g - t["table.init"], tab_u - t["table.init"]) < 5e-2, relerr(tab_g - t["table.init"], tab_u - t["table.init"])
-    assert relerr(lg, t["losses"][:4]) < 5e-3
+    assert relerr(lora_g, lora_u) < 2e-3
+    assert relerr(lg, torch.tensor(ref_losses)) < 5e-3
+    assert relerr(lora_g, orc.flat_params(ref_params)) < 5e-3
+    # the table after 4 Adam steps at lr 5e-3 (≈ sign steps: elements whose gradient is within f16 noise of zero flip)
+    assert relerr(tab_g - table_init, tab_u - table_init) < 0.15, relerr(tab_g - table_init, tab_u - table_init)
+    assert relerr(tab_g - table_init, ref_table.detach() - table_init) < 0.15, relerr(tab_g - table_init, ref_table.detach() - table_init)
 
 
 def test_full_size_cfg5_pti_step_with_token_embeddings_vs_cpu_oracle(relerr):
