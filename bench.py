@@ -41,8 +41,6 @@ def parse():
                     help="time ONLY the unchanged reference trainer loop (no LoraTrainer): what extra.drop_in reports")
     ap.add_argument("--mask", action="store_true", help="masked loss (cli_lora_pti.py:222-247) on a random binary mask")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32"])
-    ap.add_argument("--channels-last", action="store_true",
-                    help="caller-side experiment: run the UNet's convolution trunk in channels-last (NHWC) memory format")
     ap.add_argument("--no-prof", action="store_true", help="do not attach kernel events in the timed region")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel from the host each step instead of replaying the recorded hipGraph")
@@ -330,8 +328,6 @@ def run_workload(args, cfg_id, rank, world, device, dist, profile=True):
         cfg["latent"] = args.latent if args.latent is not None else cfg["latent"]
     dtype = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[args.dtype]
     unet = build_unet(device, dtype, cfg["rank"], cfg["unet"])
-    if args.channels_last:
-        unet = unet.to(memory_format=torch.channels_last)
     te = build_text_encoder(device, dtype, cfg["rank"], cfg["text_encoder"]) if cfg["text_encoder"] else None
     # forward+backward(+factor gradients) of a step are recorded once into a hipGraph (during the priming step) and
     # replayed; the RCCL exchange and the optimizer are launched from the host every step (trainer.py)

@@ -97,9 +97,71 @@ def _hip_forward(self, hidden_states, *args, **kwargs):
     return out
 
 
+def _attach_dropin_groups(module: nn.Module, valid: bool) -> None:
+    """Grouped LoRA projections for a model that is NOT under a trainer.LoraSlab — what an unchanged reference trainer gets
+    from flipping its one switch (train_lora_dreambooth.py:623-625): to_q/to_k/to_v of every self-attention as one launch each
+    way, to_k/to_v of all cross-attentions over the same context as one launch per pass (groups.py).  The members' packed
+    operands live in the ops.PackRegistry `inject_trainable_lora` made for them; their factor gradients go to the drop-in
+    sink.  A LoraTrainer built later replaces these groups with its own."""
+    from .core import LoraInjectedLinear
+    from .groups import CtxKVGroup, QKVGroup
+
+    mods = [m for m in module.modules() if _is_attention_module(m)]
+    regs = set()
+    for m in mods:
+        for key in ("_dfa_qkv", "_dfa_ctx"):
+            g = m.__dict__.get(key)
+            g = g[0] if isinstance(g, tuple) else g
+            if g is not None and g.sinks is None:  # only groups this function made (a trainer's have sinks)
+                regs.add(g.registry)
+                m.__dict__.pop(key)
+    for reg in regs:
+        if reg is not None:
+            reg.drop_groups()
+    hook = module.__dict__.pop("_dfa_ctx_pass_hook", None)
+    if hook is not None:
+        hook.remove()
+    if not valid:
+        return
+    cross = {}
+    for name, m in module.named_modules():
+        if not _is_attention_module(m) or "_dfa_qkv" in m.__dict__ or "_dfa_ctx" in m.__dict__:
+            continue
+        trio = [m.to_q, m.to_k, m.to_v]
+        if not all(type(l) is LoraInjectedLinear and "_dfa_grad_sink" not in l.__dict__ for l in trio):
+            continue
+        reg = trio[0].__dict__.get("_dfa_packreg")
+        if reg is None or any(l.__dict__.get("_dfa_packreg") is not reg for l in trio):
+            continue
+        is_cross = (m.to_k.linear.in_features != m.to_q.linear.in_features) or name.split(".")[-1] == "attn2"
+        if is_cross:
+            cross.setdefault((id(reg), m.to_k.linear.in_features, m.to_k.lora_down.weight.shape[0]), (reg, []))[1].append(m)
+        elif QKVGroup.eligible(trio):
+            grp = QKVGroup(trio, None)
+            if reg.add_group(grp):
+                m.__dict__["_dfa_qkv"] = grp
+    groups = []
+    for reg, members in cross.values():
+        layers = [l for m in members for l in (m.to_k, m.to_v)]
+        if len(members) < 2 or not CtxKVGroup.eligible(layers):
+            continue
+        grp = CtxKVGroup(members, layers, None)
+        if reg.add_group(grp):
+            for i, m in enumerate(members):
+                m.__dict__["_dfa_ctx"] = (grp, i)
+            groups.append(grp)
+    if groups:  # a new forward pass of the model starts a new shared K/V projection
+        module.__dict__["_dfa_ctx_pass_hook"] = module.register_forward_pre_hook(
+            lambda mod, args, gs=tuple(groups): [g.new_pass() for g in gs] and None)
+
+
 def set_use_hip_attention(module: nn.Module, valid: bool = True) -> int:
     """Install (valid=True) or remove (valid=False) the HIP short-context attention forward on every attention module
     under `module`.  Returns the number of modules touched.  Idempotent."""
+    import os
+
+    if os.environ.get("DFA_DROPIN_GROUPS", "1") != "0":
+        _attach_dropin_groups(module, bool(valid))
     touched = 0
     for m in module.modules():
         if not _is_attention_module(m):

@@ -83,6 +83,98 @@ def _same_scale(layers) -> Optional[float]:
     return s if all(float(l.scale) == s for l in layers) else None
 
 
+def qkv_pack_rows(grp, src_offs, base: int):
+    """Rows of the one-launch re-pack (`lora_pack_items`: {src_off, which, len, r, d16_off, d16_ld, dT_off, rows}) that fill a
+    QKVGroup's packed operands at element offset `base` of a packed buffer; src_offs[g] = (up_off, down_off) of member g's
+    fp32 factors relative to the launch's `params` pointer.  Returns (rows, (fa, qb, fb, qa), elements used)."""
+    K, N, r, G = grp.K, grp.N, grp.r, grp.G
+    rows = []
+    if grp.wide:  # every member keeps its own 16-slot factors: Fa [G][16,K] | Qb [GN,16] | Fb [16,GN] | Qa [G][K,16]
+        fa, qb, fb, qa = base, base + 16 * G * K, base + 16 * G * K + 16 * G * N, base + 16 * G * K + 32 * G * N
+        for g, (up_off, down_off) in enumerate(src_offs):
+            rows.append([down_off, 0, K, r, fa + g * 16 * K, K, qa + g * 16 * K, 16])
+            rows.append([up_off, 1, N, r, fb + g * N, G * N, qb + g * N * 16, 16])
+        return rows, (fa, qb, fb, qa), 32 * G * (K + N)
+    # block-diagonal rank-G·r factors (the buffer must have been ZEROED once: every member fills only its own rank slots)
+    fa, qb, fb, qa = base, base + 16 * K, base + 16 * K + 16 * G * N, base + 16 * K + 32 * G * N
+    for g, (up_off, down_off) in enumerate(src_offs):
+        rows.append([down_off, 0, K, r, fa + g * r * K, K, qa + g * r, r])
+        rows.append([up_off, 1, N, r, fb + g * r * G * N + g * N, G * N, qb + g * N * 16 + g * r, r])
+    return rows, (fa, qb, fb, qa), 32 * K + 32 * G * N
+
+
+def bind_qkv_views(grp, pk, spec):
+    fa, qb, fb, qa = spec
+    GN = grp.G * grp.N
+    nk = 16 * grp.K * (grp.G if grp.wide else 1)
+    grp.Fa, grp.Qb, grp.Fb, grp.Qa = pk[fa:fa + nk], pk[qb:qb + 16 * GN], pk[fb:fb + 16 * GN], pk[qa:qa + nk]
+
+
+def ctx_pack_rows(grp, src_offs, base: int):
+    """The same for a CtxKVGroup: A16 [G][16,K] | B16 [ΣN,16] | Bt16 [part g: [16, N_g] at 16·off_g]."""
+    K, r, G = grp.K, grp.r, grp.G
+    a16, b16, bt = base, base + 16 * G * K, base + 16 * G * K + 16 * grp.total
+    rows = []
+    grp.bt_off = []
+    for g, (up_off, down_off) in enumerate(src_offs):
+        rows.append([down_off, 0, K, r, a16 + g * 16 * K, K, -1, 16])
+        rows.append([up_off, 1, grp.N[g], r, bt + 16 * grp.off[g], grp.N[g], b16 + 16 * grp.off[g], 16])
+        grp.bt_off.append(16 * grp.off[g])
+    return rows, (a16, b16, bt), 16 * G * K + 32 * grp.total
+
+
+def bind_ctx_views(grp, pk, spec):
+    a16, b16, bt = spec
+    grp.A16 = pk[a16:a16 + 16 * grp.G * grp.K]
+    grp.B16 = pk[b16:b16 + 16 * grp.total]
+    grp.Bt16 = pk[bt:bt + 16 * grp.total]
+
+
+class _GradTargets:
+    """Where a group's factor-gradient problems go.  Under a trainer: the slab's batched launch, outputs = the members' slots
+    of the partial-sum slab.  Without one (an unchanged reference trainer calling loss.backward()): the drop-in sink, outputs =
+    the members' Parameters (ops._AutoSink hands them their .grad when the backward pass ends)."""
+
+    def __init__(self, group):
+        self.g = group
+
+    def note(self, M, need_dx):
+        if self.g.sinks is not None:
+            slab = self.g.sinks[0].slab
+            for sink in self.g.sinks:
+                slab.note_layer(sink.index, M, need_dx)
+
+    def defer(self, members, up: bool, S, s_off, s_stride, C, P, p_off, p_stride, M, scale, keep):
+        g = self.g
+        r = g.r
+        if g.sinks is not None:
+            slab = g.sinks[0].slab
+            outs = [(g.sinks[i].up_ptr if up else g.sinks[i].down_ptr) for i in members]
+            slab.defer(nat.grad_problem(S, s_off, s_stride, C, P, p_off, p_stride, len(members) * r, outs, r, not up,
+                                        slab.stride, M, scale), g.sinks[members[0]].index if up else None, keep)
+        else:
+            from .ops import _auto_sink_for
+
+            lay = g.layers[members[0]]
+            sink = _auto_sink_for(lay.lora_down.weight, lay.lora_up.weight)
+            targets = [((g.layers[i].lora_up.weight if up else g.layers[i].lora_down.weight), torch.float32) for i in members]
+            sink.defer_problem(S, s_off, s_stride, C, P, p_off, p_stride, r, not up, M, scale, targets)
+
+
+def _dropin_ready(group, cdtype) -> bool:
+    """A group without a slab: its packed operands come from the members' ops.PackRegistry (refreshed here when a factor
+    changed) and its gradients go to the drop-in sink — which must exist for every member (no process group, no hooks)."""
+    from .ops import _auto_sink_for
+
+    reg = group.registry
+    if reg is None:
+        return False
+    for l in group.layers:
+        if _auto_sink_for(l.lora_down.weight, l.lora_up.weight) is None:
+            return False
+    return reg.ensure(group.layers, cdtype)
+
+
 class QKVGroup:
     """to_q / to_k / to_v of one self-attention module.  Packed operands (views into the slab's packed buffer):
          Fa [16,K]   rows g·r+j = A_g[j,:]           (forward main-loop factor)
@@ -96,14 +188,17 @@ class QKVGroup:
     T / U keep the [M, 3r] layout (member g in columns g·r ..) either way."""
 
     def __init__(self, layers, sinks):
-        self.layers, self.sinks = list(layers), list(sinks)
+        self.layers, self.sinks = list(layers), (None if sinks is None else list(sinks))
         lin = layers[0].linear
         self.K, self.N = lin.in_features, lin.out_features
         self.r = layers[0].lora_down.weight.shape[0]
         self.G = len(layers)
         self.wide = self.G * self.r > RANK_PAD
         self.frozen = _FrozenCat(self.layers)
-        self.Fa = self.Qb = self.Fb = self.Qa = None  # set by LoraSlab.enable_packed
+        self.Fa = self.Qb = self.Fb = self.Qa = None  # set by LoraSlab.enable_packed (or by the members' PackRegistry)
+        self.registry = None                          # drop-in mode (sinks is None): ops.PackRegistry that owns the operands
+        self.Fb_part = None
+        self.grads = _GradTargets(self)
 
     @staticmethod
     def eligible(layers) -> bool:
@@ -123,6 +218,8 @@ class QKVGroup:
     def usable(self, x: torch.Tensor, cdtype: torch.dtype) -> bool:
         if self.wide and cdtype == torch.float32:
             return False  # the part-wise kernels are 16-bit (fp32 parity runs keep the members on their own)
+        if self.sinks is None and not (x.is_cuda and _dropin_ready(self, cdtype)):
+            return False
         return (self.Fa is not None and self.Fa.dtype == cdtype and x.is_cuda and _same_scale(self.layers) is not None
                 and all(not l.linear.weight.requires_grad for l in self.layers))
 
@@ -190,21 +287,16 @@ class _QKVProjFn(torch.autograd.Function):
                                      M, N, 0, r, ctx.scale)
         else:
             nat.lora_gemm_packed(d2, N3, None, None, g.Fb, None, None, None, 0, None, u, M, N3, 0, rr, ctx.scale)
-        slab = g.sinks[0].slab
-        stride = slab.stride
-        for sink in g.sinks:
-            slab.note_layer(sink.index, M, need_dx)
-        for i, sink in enumerate(g.sinks):  # gB_i = s·dY_iᵀ·T_i : column slices of the shared buffers
-            slab.defer(nat.grad_problem(d2, i * N, N3, N, t, i * r, rr, r, [sink.up_ptr], r, False, stride, M, ctx.scale),
-                       sink.index, (d2, t))
+        g.grads.note(M, need_dx)
+        for i in range(g.G):  # gB_i = s·dY_iᵀ·T_i : column slices of the shared buffers
+            g.grads.defer([i], True, d2, i * N, N3, N, t, i * r, rr, M, ctx.scale, (d2, t))
         # gA = s·Uᵀ·X: as many members per problem as fit 16 accumulator columns (rank groups of r → their `down` gradients);
         # all three at rank <= 5 — X read once — two + one at rank 8, one each at rank 16
         per = 1 if u_by_part else max(1, RANK_PAD // r)
         for c in range(0, g.G, per):
-            mem = g.sinks[c:c + per]
+            mem = list(range(c, min(c + per, g.G)))
             off, ld = (c * M * r, r) if u_by_part else (c * r, rr)
-            slab.defer(nat.grad_problem(x2, 0, K, K, u, off, ld, len(mem) * r, [s_.down_ptr for s_ in mem], r, True, stride,
-                                        M, ctx.scale), None, (x2, u))
+            g.grads.defer(mem, False, x2, 0, K, K, u, off, ld, M, ctx.scale, (x2, u))
         dx = None
         if need_dx:
             dx = dx2.view(ctx.x_shape)
@@ -296,7 +388,7 @@ class CtxKVGroup:
     carries a gradient (a training text encoder / training token embeddings) — one launch for its dX."""
 
     def __init__(self, modules, layers, sinks):
-        self.modules, self.layers, self.sinks = list(modules), list(layers), list(sinks)
+        self.modules, self.layers, self.sinks = list(modules), list(layers), (None if sinks is None else list(sinks))
         self.G = len(self.layers)
         self.K = self.layers[0].linear.in_features
         self.r = self.layers[0].lora_down.weight.shape[0]
@@ -307,7 +399,9 @@ class CtxKVGroup:
             o += n
         self.total = o
         self.frozen = _FrozenCat(self.layers)
-        self.A16 = self.B16 = self.Bt16 = None  # packed operands: set by LoraSlab.enable_packed
+        self.A16 = self.B16 = self.Bt16 = None  # packed operands: set by LoraSlab.enable_packed (or the members' PackRegistry)
+        self.registry = None                     # drop-in mode (sinks is None)
+        self.grads = _GradTargets(self)
         self.bt_off: List[int] = []              # element offset of part g's Bt16 [16, N_g] inside self.Bt16
         self.tile_part = None
         self._part_tables = {}
@@ -344,6 +438,9 @@ class CtxKVGroup:
         # buffers belong to a whole forward pass, not to a block.  Those cross-attentions project their own K / V
         # (per-module path); the reentrant form's no-grad forward and every ordinary pass use the group.
         if _in_backward() or _saved_tensor_hooks_active():
+            return False
+        # (drop-in mode: the members' packed operands are checked once per pass — by the cross-attention that projects)
+        if self.sinks is None and self._pass is None and not (ctx_t.is_cuda and _dropin_ready(self, cdtype)):
             return False
         # (a context that carries a gradient — a text encoder that trains, train_lora_dreambooth.py:608-621, or whose token
         #  embeddings do, cli_lora_pti.py:706-722 — gets its dX from ONE grouped launch as well: _CtxProjFn.backward)
@@ -424,14 +521,10 @@ class _CtxProjFn(torch.autograd.Function):
             acat = torch.cat([l.lora_down.weight.detach().float() for l in g.layers])      # [G·r, K]
             de = torch.addmm(de2.float(), u.permute(1, 0, 2).reshape(M, g.G * r), acat, alpha=ctx.scale)
             de = de.to(ctx.e_dtype).view(ctx.e_shape)
-        slab = g.sinks[0].slab
-        stride = slab.stride
-        for i, sink in enumerate(g.sinks):
-            slab.note_layer(sink.index, M, need_dx)
-            slab.defer(nat.grad_problem(d2, g.off[i], g.total, g.N[i], t, i * M * r, r, r, [sink.up_ptr], r, False,
-                                        stride, M, ctx.scale), sink.index, (d2, t))
-            slab.defer(nat.grad_problem(e2, 0, g.K, g.K, u, i * M * r, r, r, [sink.down_ptr], r, True, stride, M,
-                                        ctx.scale), None, (e2, u))
+        g.grads.note(M, need_dx)
+        for i in range(g.G):
+            g.grads.defer([i], True, d2, g.off[i], g.total, g.N[i], t, i * M * r, r, M, ctx.scale, (d2, t))
+            g.grads.defer([i], False, e2, 0, g.K, g.K, u, i * M * r, r, M, ctx.scale, (e2, u))
         return (de, None, None, None) + (None,) * (2 * g.G)
 
 

@@ -128,7 +128,17 @@ class _AutoSink:
         self.tables = {}
 
     def defer(self, dy2, x2, t, u, scale, down, up, dtypes):
-        self.items.append((dy2, x2, t, u, scale, down, up, dtypes))
+        """One layer: gB = s·dYᵀ·T → up, gA = s·Uᵀ·X → down."""
+        M, N = dy2.shape
+        K, r = x2.shape[1], t.shape[1]
+        self.defer_problem(dy2, 0, N, N, t, 0, r, r, False, M, scale, [(up, dtypes[1])])
+        self.defer_problem(x2, 0, K, K, u, 0, r, r, True, M, scale, [(down, dtypes[0])])
+
+    def defer_problem(self, S, s_off, s_stride, C, P, p_off, p_stride, rg, out_kn, M, scale, targets):
+        """G[c, j] = scale·Σ_m S[m, s_off + c]·P[m, p_off + j] for len(targets)·rg rank columns; rank group i (rg columns) is
+        the whole gradient of the Parameter targets[i][0] ([C, rg] for an `up`, [rg, C] for a `down` — out_kn), handed over
+        in targets[i][1].  Operands may be column slices of wider buffers (grouped projections)."""
+        self.items.append((S, s_off, s_stride, C, P, p_off, p_stride, rg, out_kn, M, scale, targets))
         if not self.armed:
             self.armed = True
             torch.autograd.Variable._execution_engine.queue_callback(self.flush)
@@ -138,10 +148,10 @@ class _AutoSink:
         if not items:
             return
         offs, total = [], 0
-        for dy2, x2, t, u, *_ in items:
-            n = t.shape[1] * (dy2.shape[1] + x2.shape[1])
+        for it in items:
+            C, rg, targets = it[3], it[7], it[11]
             offs.append(total)
-            total += n
+            total += len(targets) * rg * C
         stride = (total + 3) // 4 * 4
         if self.partials is None or self.partials.shape[1] < stride:
             self.partials = torch.empty((nat.GRAD_MAX_BLOCKS, stride), dtype=torch.float32, device=self.device)
@@ -149,13 +159,12 @@ class _AutoSink:
         grads = torch.empty(stride, dtype=torch.float32, device=self.device)
         base = part.data_ptr()
         by_dtype, rows = {}, []
-        for off, (dy2, x2, t, u, scale, _, _, _) in zip(offs, items):
-            M, N = dy2.shape
-            K, r = x2.shape[1], t.shape[1]
-            probs = by_dtype.setdefault(dy2.dtype, [])
-            probs.append(nat.grad_problem(dy2, 0, N, N, t, 0, r, r, [base + 4 * off], r, False, pstride, M, scale))
-            probs.append(nat.grad_problem(x2, 0, K, K, u, 0, r, r, [base + 4 * (off + N * r)], r, True, pstride, M, scale))
-            rows.append([off, r * (N + K), nat.grad_row_blocks(M), 0])
+        for off, (S, s_off, s_stride, C, P, p_off, p_stride, rg, out_kn, M, scale, targets) in zip(offs, items):
+            n = len(targets)
+            outs = [base + 4 * (off + i * rg * C) for i in range(n)]
+            by_dtype.setdefault(S.dtype, []).append(
+                nat.grad_problem(S, s_off, s_stride, C, P, p_off, p_stride, n * rg, outs, rg, out_kn, pstride, M, scale))
+            rows.append([off, n * rg * C, nat.grad_row_blocks(M), 0])
         for dt, probs in by_dtype.items():
             nat.lora_grad_batched(probs, dt, self.device)
         key = tuple(map(tuple, rows))
@@ -163,12 +172,12 @@ class _AutoSink:
         if table is None:
             table = self.tables[key] = torch.tensor(rows, dtype=torch.int64).to(self.device)
         nat.lora_fold_partials(table, len(rows), max(r_[1] for r_ in rows), part, pstride, grads, False)
-        for off, (dy2, x2, t, u, _, down, up, dtypes) in zip(offs, items):
-            N, K, r = dy2.shape[1], x2.shape[1], t.shape[1]
-            for p, g, dt in ((up, grads[off:off + N * r].view(N, r), dtypes[1]),
-                             (down, grads[off + N * r:off + r * (N + K)].view(r, K), dtypes[0])):
+        for off, it in zip(offs, items):
+            C, rg, out_kn, targets = it[3], it[7], it[8], it[11]
+            for i, (p, dt) in enumerate(targets):
                 if not p.requires_grad:
                     continue  # (a factor frozen by the caller: autograd would not have produced its gradient either)
+                g = grads[off + i * rg * C: off + (i + 1) * rg * C].view((rg, C) if out_kn else (C, rg))
                 if dt != torch.float32:
                     g = g.to(dt)
                 if p.grad is None:
@@ -181,7 +190,9 @@ class PackRegistry:
     """Drop-in mode (no trainer.LoraSlab): the packed compute-dtype factors of ALL layers one `inject_trainable_lora` call
     wrapped, refreshed by ONE `lora_pack_items` launch when a forward finds its own factors changed (an optimizer step, a
     loaded file, `.to()`) instead of one `lora_pack_factors` launch + two allocations per layer call.  What the reference pays
-    at this point is autocast's per-call cast of `lora_down/lora_up.weight` (lora.py:50 under train_lora_dreambooth.py:489-494)."""
+    at this point is autocast's per-call cast of `lora_down/lora_up.weight` (lora.py:50 under train_lora_dreambooth.py:489-494).
+    It also owns the packed operands of the GROUPED projections an unchanged trainer gets (groups.QKVGroup / CtxKVGroup built
+    by the attention switch, attention.set_use_hip_attention): their rows ride in the same launch."""
 
     def __init__(self, modules):
         self.modules = [m for m in modules if m.lora_down.weight.shape[0] <= 16]
@@ -190,10 +201,32 @@ class PackRegistry:
         self.views = None
         self.table = None
         self.ptrs = None
+        self.groups = []
 
-    def _signature(self):
-        return tuple((m.lora_down.weight.data_ptr(), m.lora_down.weight._version, m.lora_up.weight.data_ptr(),
-                      m.lora_up.weight._version) for m in self.modules)
+    def add_group(self, grp) -> bool:
+        """A grouped projection whose members all live in this registry; its operands are laid out at the next refresh."""
+        if not all(id(l) in self.index for l in grp.layers):
+            return False
+        grp.registry = self
+        self.groups.append(grp)
+        self.table = None
+        return True
+
+    def drop_groups(self):
+        for grp in self.groups:
+            grp.registry = None
+        self.groups = []
+        self.table = None
+
+    @staticmethod
+    def _sig(m):
+        d, u = m.lora_down.weight, m.lora_up.weight
+        return (d.data_ptr(), d._version, u.data_ptr(), u._version)
+
+    def _current(self, members, cdtype, device) -> bool:
+        st = self.state
+        return (st is not None and self.table is not None and st[0] == cdtype and st[1] == device and
+                all(st[2][self.index[id(m)]] == self._sig(m) for m in members))
 
     def get(self, module, cdtype):
         i = self.index.get(id(module))
@@ -202,13 +235,20 @@ class PackRegistry:
         d, u = module.lora_down.weight, module.lora_up.weight
         if d.dtype != torch.float32 or u.dtype != torch.float32 or not d.is_cuda:
             return None  # (factors held in another dtype are cast per call, as before)
-        st = self.state
-        if st is None or st[0] != cdtype or st[1] != d.device or st[2][i] != (d.data_ptr(), d._version, u.data_ptr(), u._version):
-            if not self._repack(cdtype, d.device):
-                return None
+        if not self._current((module,), cdtype, d.device) and not self._repack(cdtype, d.device):
+            return None
         return self.views[i]
 
+    def ensure(self, members, cdtype) -> bool:
+        """True when the packed operands (a group's included) are current for `members` — refreshing them if needed."""
+        d = members[0].lora_down.weight
+        if d.dtype != torch.float32 or not d.is_cuda:
+            return False
+        return self._current(members, cdtype, d.device) or self._repack(cdtype, d.device)
+
     def _repack(self, cdtype, device):
+        from .groups import QKVGroup, bind_ctx_views, bind_qkv_views, ctx_pack_rows, qkv_pack_rows
+
         mods = self.modules
         if any(m.lora_down.weight.dtype != torch.float32 or m.lora_down.weight.device != device or
                not m.lora_down.weight.is_contiguous() or not m.lora_up.weight.is_contiguous() for m in mods):
@@ -220,24 +260,38 @@ class PackRegistry:
             # element offsets relative to ONE base pointer: the factors live in separate allocations, the pack kernel adds a
             # signed 64-bit offset to its `params` argument
             base = mods[0].lora_down.weight
+
+            def rel(p):
+                return (p.data_ptr() - base.data_ptr()) // 4
+
             rows, views_at, off = [], [], 0
             for m in mods:
                 r, K = m.lora_down.weight.shape
                 N = m.lora_up.weight.shape[0]
-                rows.append([(m.lora_down.weight.data_ptr() - base.data_ptr()) // 4, 0, K, r, off, K, off + 16 * K, 16])
-                rows.append([(m.lora_up.weight.data_ptr() - base.data_ptr()) // 4, 1, N, r, off + 32 * K, N,
-                             off + 32 * K + 16 * N, 16])
+                rows.append([rel(m.lora_down.weight), 0, K, r, off, K, off + 16 * K, 16])
+                rows.append([rel(m.lora_up.weight), 1, N, r, off + 32 * K, N, off + 32 * K + 16 * N, 16])
                 views_at.append((off, K, N))
                 off += 32 * (K + N)
-            self.packed = torch.empty(off, dtype=cdtype, device=device)
+            binds = []
+            for grp in self.groups:
+                src = [(rel(l.lora_up.weight), rel(l.lora_down.weight)) for l in grp.layers]
+                qkv = isinstance(grp, QKVGroup)
+                g_rows, spec, used = (qkv_pack_rows if qkv else ctx_pack_rows)(grp, src, off)
+                rows += g_rows
+                binds.append((grp, spec, bind_qkv_views if qkv else bind_ctx_views, qkv))
+                off += used
+            self.packed = torch.zeros(off, dtype=cdtype, device=device)  # zeroed: block-diagonal groups fill their own slots only
             self.table = torch.tensor(rows, dtype=torch.int64).to(device)
             self.maxlen = max(r_[2] for r_ in rows)
             self.views = [(self.packed[o:o + 32 * K], self.packed[o + 32 * K:o + 32 * (K + N)]) for o, K, N in views_at]
+            for grp, spec, bind, qkv in binds:
+                bind(grp, self.packed, spec)
+                if qkv:
+                    grp.Fb_part = [self.views[self.index[id(l)]][1][:16 * grp.N] for l in grp.layers]
             self.ptrs = ptrs
             self.base = base
         nat.lora_pack_items(self.table, self.table.shape[0], self.maxlen, self.base.detach(), self.packed)
-        self.state = (cdtype, device, tuple((m.lora_down.weight.data_ptr(), m.lora_down.weight._version,
-                                             m.lora_up.weight.data_ptr(), m.lora_up.weight._version) for m in mods))
+        self.state = (cdtype, device, tuple(self._sig(m) for m in mods))
         return True
 
 

@@ -185,6 +185,8 @@ class LoraSlab:
         """Allocates the packed-factor buffer — per layer Apack (32·K) and Bpack (32·N) in the compute dtype, both
         orientations (lora_hip.h), plus the operands of the grouped projections — and the device table for the one-launch
         re-pack (lora_pack_items: one row per factor and destination)."""
+        from .groups import bind_ctx_views, bind_qkv_views, ctx_pack_rows, qkv_pack_rows
+
         rows, off = [], 0
         layer_views = []
         for i, layer in enumerate(self.layers):
@@ -200,38 +202,20 @@ class LoraSlab:
             off += 32 * (K + N)
         index_of = {id(l): i for i, l in enumerate(self.layers)}
         group_views = []
+
+        def src_offs(grp):  # (up_off, down_off) of every member's fp32 factors inside the slab
+            return [(self.offsets[2 * index_of[id(l)]][0], self.offsets[2 * index_of[id(l)] + 1][0]) for l in grp.layers]
+
         for grp in self.qkv_groups:
-            K, N, r, G = grp.K, grp.N, grp.r, grp.G
-            if grp.wide:  # every member keeps its own 16-slot factors (groups.QKVGroup): Fa [G][16,K] | Qb [GN,16] | Fb [16,GN] | Qa [G][K,16]
-                fa, qb, fb, qa = off, off + 16 * G * K, off + 16 * G * K + 16 * G * N, off + 16 * G * K + 32 * G * N
-                for g, layer in enumerate(grp.layers):
-                    i = index_of[id(layer)]
-                    up_off, down_off = self.offsets[2 * i][0], self.offsets[2 * i + 1][0]
-                    rows.append([down_off, 0, K, r, fa + g * 16 * K, K, qa + g * 16 * K, 16])
-                    rows.append([up_off, 1, N, r, fb + g * N, G * N, qb + g * N * 16, 16])
-                group_views.append((grp, fa, qb, fb, qa))
-                off += 32 * G * (K + N)
-                continue
-            fa, qb, fb, qa = off, off + 16 * K, off + 16 * K + 16 * G * N, off + 16 * K + 32 * G * N
-            for g, layer in enumerate(grp.layers):
-                i = index_of[id(layer)]
-                up_off, down_off = self.offsets[2 * i][0], self.offsets[2 * i + 1][0]
-                rows.append([down_off, 0, K, r, fa + g * r * K, K, qa + g * r, r])
-                rows.append([up_off, 1, N, r, fb + g * r * G * N + g * N, G * N, qb + g * N * 16 + g * r, r])
-            group_views.append((grp, fa, qb, fb, qa))
-            off += 32 * K + 32 * G * N
+            g_rows, spec, used = qkv_pack_rows(grp, src_offs(grp), off)
+            rows += g_rows
+            group_views.append((grp, spec, bind_qkv_views))
+            off += used
         for grp in self.ctx_groups:
-            K, r, G = grp.K, grp.r, grp.G
-            a16, b16, bt = off, off + 16 * G * K, off + 16 * G * K + 16 * grp.total
-            grp.bt_off = []
-            for g, layer in enumerate(grp.layers):
-                i = index_of[id(layer)]
-                up_off, down_off = self.offsets[2 * i][0], self.offsets[2 * i + 1][0]
-                rows.append([down_off, 0, K, r, a16 + g * 16 * K, K, -1, 16])
-                rows.append([up_off, 1, grp.N[g], r, bt + 16 * grp.off[g], grp.N[g], b16 + 16 * grp.off[g], 16])
-                grp.bt_off.append(16 * grp.off[g])
-            group_views.append((grp, a16, b16, bt))
-            off += 16 * G * K + 32 * grp.total
+            g_rows, spec, used = ctx_pack_rows(grp, src_offs(grp), off)
+            rows += g_rows
+            group_views.append((grp, spec, bind_ctx_views))
+            off += used
         if not rows:
             self.packed = None
             return
@@ -243,18 +227,8 @@ class LoraSlab:
             layer.__dict__["_dfa_packed"] = (pk[o:o + 32 * K], pk[o + 32 * K:o + 32 * (K + N)])
         for grp in self.qkv_groups:  # the members' own Bt16 [16,N] tiles (P-only launches of a wide group without dX)
             grp.Fb_part = [l.__dict__["_dfa_packed"][1][:16 * grp.N] for l in grp.layers]
-        for view in group_views:
-            grp = view[0]
-            if len(view) == 5:
-                _, fa, qb, fb, qa = view
-                K, GN = grp.K, grp.G * grp.N
-                nk = 16 * K * (grp.G if grp.wide else 1)
-                grp.Fa, grp.Qb, grp.Fb, grp.Qa = pk[fa:fa + nk], pk[qb:qb + 16 * GN], pk[fb:fb + 16 * GN], pk[qa:qa + nk]
-            else:
-                _, a16, b16, bt = view
-                grp.A16 = pk[a16:a16 + 16 * grp.G * grp.K]
-                grp.B16 = pk[b16:b16 + 16 * grp.total]
-                grp.Bt16 = pk[bt:bt + 16 * grp.total]
+        for grp, spec, bind in group_views:
+            bind(grp, pk, spec)
         self.repack()
 
     def repack(self):

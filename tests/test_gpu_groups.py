@@ -741,3 +741,62 @@ def test_clip_attention_projections_share_one_launch(relerr, monkeypatch):
     _, want8, lu8, _ = train(False, 8)
     assert relerr(l8, lu8) < 2e-3 and relerr(got8, want8) < 2e-3, (relerr(l8, lu8), relerr(got8, want8))
     assert torch.isfinite(l8).all()
+
+
+@pytest.mark.parametrize("r", [4, 8])
+def test_unchanged_trainer_loop_gets_grouped_projections(relerr, monkeypatch, r):
+    """The reference's loop as written (train_lora_dreambooth.py:595-598,623-625,659-676,811-888 under fp16 mixed precision):
+    fp32 module under autocast, inject_trainable_lora, the attention switch, torch.optim.AdamW over the chained generators,
+    F.mse_loss, GradScaler, clip_grad_norm_ — no LoraTrainer, no slab.  Flipping the switch now also groups the projections:
+    q/k/v of every self-attention in one launch each way, K/V of all cross-attentions in one launch per pass, operands from
+    the PackRegistry, gradients through the drop-in sink.  `.grad` of every LoRA Parameter after one loss.backward() and the
+    3-step trajectory must equal the ungrouped ones (DFA_DROPIN_GROUPS=0)."""
+    import torch.nn.functional as F
+
+    def run(grouped):
+        monkeypatch.setenv("DFA_DROPIN_GROUPS", "1" if grouped else "0")
+        unet = _tiny64().to(DEV)
+        params, _ = dfa.inject_trainable_lora(unet, r=r)
+        plist = list(itertools.chain(*params))
+        _warm(plist)
+        set_use_memory_efficient_attention_xformers(unet, True)
+        calls = {"packed": 0, "parts": 0}
+        real_p, real_q = nat.lora_gemm_packed, nat.lora_gemm_parts
+        monkeypatch.setattr(nat, "lora_gemm_packed", lambda *a, **k: (calls.__setitem__("packed", calls["packed"] + 1), real_p(*a, **k))[1])
+        monkeypatch.setattr(nat, "lora_gemm_parts", lambda *a, **k: (calls.__setitem__("parts", calls["parts"] + 1), real_q(*a, **k))[1])
+        opt = torch.optim.AdamW(plist, lr=1e-3)
+        scaler = torch.amp.GradScaler("cuda", init_scale=256.0)
+        first, losses = None, []
+        for step in range(3):
+            lat, noise, ts, ctx = orc.synthetic_batch(step, 2, 8, 6, 64)
+            with torch.autocast("cuda", dtype=torch.float16):
+                pred = unet(lat.to(DEV), ts.to(DEV), ctx.to(DEV)).sample
+            loss = F.mse_loss(pred.float(), noise.to(DEV).float(), reduction="mean")
+            scaler.scale(loss).backward()
+            scaler.unscale_(opt)
+            if first is None:
+                first = torch.cat([p.grad.reshape(-1) for p in plist]).cpu()
+            torch.nn.utils.clip_grad_norm_(plist, 1.0)
+            scaler.step(opt)
+            scaler.update()
+            opt.zero_grad()
+            losses.append(loss.item())
+        monkeypatch.setattr(nat, "lora_gemm_packed", real_p)
+        monkeypatch.setattr(nat, "lora_gemm_parts", real_q)
+        groups = [m.__dict__.get("_dfa_qkv") for m in unet.modules() if "_dfa_qkv" in m.__dict__]
+        ctxg = {id(m.__dict__["_dfa_ctx"][0]) for m in unet.modules() if "_dfa_ctx" in m.__dict__}
+        return first, torch.cat([p.detach().reshape(-1) for p in plist]).cpu(), torch.tensor(losses), calls, groups, ctxg
+
+    g1, state_g, lg, calls_g, groups, ctxg = run(True)
+    assert len(groups) == 4 and all(g.sinks is None and g.registry is not None and g.wide == (3 * r > 16) for g in groups)
+    assert len(ctxg) == 1
+    # 3 steps × (4 q/k/v groups × (fwd + bwd-input) + 1 context K/V forward + 1 P-only backward)
+    n_qkv = 3 * 4 * 2
+    if 3 * r > 16:
+        assert calls_g["parts"] == n_qkv - 3 and calls_g["packed"] == 3 * 2 + 3 * 3  # first block: no dX → three P-only launches
+    else:
+        assert calls_g["parts"] == 0 and calls_g["packed"] == n_qkv + 3 * 2
+    u1, state_u, lu, calls_u, groups_u, _ = run(False)
+    assert not groups_u and calls_u == {"packed": 0, "parts": 0}
+    assert relerr(g1, u1) < 2e-3, relerr(g1, u1)
+    assert relerr(lg, lu) < 2e-3 and relerr(state_g, state_u) < 2e-3, (relerr(lg, lu), relerr(state_g, state_u))
