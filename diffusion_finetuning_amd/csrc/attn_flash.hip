@@ -123,6 +123,29 @@ __device__ __forceinline__ float quad_sum(float x) {
     return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
+// max of the 16 scores a lane holds for one row block, as a tree of three-input maxima (v_max3_f32): 8 instructions instead of
+// the 16-long chain the scalar loop compiles to
+__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+__device__ __forceinline__ float max16(const f32x4 (&s)[kNKF]) {
+    const float a = max3f(s[0][0], s[0][1], s[0][2]), b = max3f(s[0][3], s[1][0], s[1][1]);
+    const float c = max3f(s[1][2], s[1][3], s[2][0]), d = max3f(s[2][1], s[2][2], s[2][3]);
+    const float e = max3f(s[3][0], s[3][1], s[3][2]);
+    return __builtin_fmaxf(max3f(a, b, c), max3f(d, e, s[3][3]));
+}
+
+// Softmax scale folded into the operand: q·(scale·log2 e), rounded to the storage type ONCE per kernel.  Together with a row
+// constant as the INITIAL accumulator of the score MFMAs (−m, −LSE, −Δ) the exponent's argument leaves the matrix pipe
+// ready: p = exp2(acc) — no per-score fma / subtraction on the VALU (cdna_hip_programming.md, attention backward: "row
+// constants as the initial accumulator").  The extra rounding of q (2^-11 relative in f16) moves the result by about as much
+// as the storage rounding of q itself: 2e-4 → 3e-4 relative against float64 at the SD shapes (tolerance of the tests: 2e-3).
+template <typename T, int KS>
+__device__ __forceinline__ void prescale_frags(typename Mma<T>::F8 (&f)[KS], float c) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[ks][e] = from_f32<T>(to_f32<T>(f[ks][e]) * c);
+}
+
 // ONES (head dims that leave padding rows in the Vᵀ tile, d % 16 == 8: the 40-wide heads of SD1.5's widest level): row d of
 // Vᵀ is set to ones once, so the P·V product itself accumulates Σp — on the matrix pipe, in fp32, rescaled together with
 // the output — and the 64 VALU adds and two cross-lane reductions per row block and tile disappear.
@@ -153,9 +176,10 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restr
     for (int rb = 0; rb < RB; ++rb) {
         const int t = row0 + rb * 16 + l15;
         load_row_frags<T, KS>(Qh + (int64_t)t * ldq, Qh, t < Tq, d, lq, qf[rb]);
+        prescale_frags<T, KS>(qf[rb], scale_log2e);  // scores come out of the MFMA in the exp2 domain
     }
     f32x4 o[RB][DF];
-    float m[RB], l[RB];
+    float m[RB], l[RB];  // m: reference maximum of the row (exp2 domain), −inf until the first tile has set it
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
         m[rb] = -INFINITY;
@@ -191,6 +215,56 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restr
         const T* Vc = Vs + cur * S::K_HALFS;
         if (kt + 1 < n_tiles) stage.load(Kh + (int64_t)(kt + 1) * kTile * ldq, Vh + (int64_t)(kt + 1) * kTile * ldq, Tk - (kt + 1) * kTile);  // in flight during this tile's work
 
+        // ---- online softmax of one 16-row block, one query row per lane.  `sc` holds s·c − m (the MFMA chain started at −m:
+        // see scores()), so a probability is ONE v_exp_f32 of an accumulator register.  Lazy rescaling: the reference maximum
+        // moves only when a row outgrows it by more than 2^8 (or has none yet) — after the first tiles almost never — so the
+        // correction exp2, the DF·4 accumulator multiplies and the per-score subtraction run on very few tiles.  Probabilities
+        // reach at most 2^8 (exact in fp32, far inside the 16-bit operand's range); O = o / l and LSE = m + log2 l do not depend
+        // on which m was used.  Only the rows that outgrew their reference move it (the others shift by 0): a row's result
+        // never depends on which other rows share its wave.
+        auto softmax_block = [&](int rb, f32x4 (&sc)[kNKF], int kt_) {
+            if constexpr (RAGGED) {  // keys past Tk never win the max and get probability 0
+                const int key_base = kt_ * kTile + lq * 4;
+    #pragma unroll
+                for (int nf = 0; nf < kNKF; ++nf)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (key_base + nf * 16 + r >= Tk) sc[nf][r] = -INFINITY;
+            }
+            const float mt = quad_max(max16(sc));  // relative to the reference maximum
+            const bool fresh = m[rb] == -INFINITY;
+            const bool move = fresh || mt > 8.f;
+            float sum = 0.f;
+            if (__any(move)) {
+                const float base = fresh ? 0.f : m[rb];
+                const float m_new = move ? base + mt : m[rb];
+                const float shift = m_new - base;                       // 0 for the rows that keep their reference
+                const float alpha = fresh ? 1.f : fast_exp2(-shift);    // (o and l of a fresh row are still zero)
+                m[rb] = m_new;
+                l[rb] *= alpha;
+    #pragma unroll
+                for (int df = 0; df < DF; ++df) o[rb][df] *= alpha;
+    #pragma unroll
+                for (int nf = 0; nf < kNKF; ++nf)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = fast_exp2(sc[nf][r] - shift);
+                        sc[nf][r] = p;
+                        if constexpr (!ONES) sum += p;
+                    }
+            } else {
+    #pragma unroll
+                for (int nf = 0; nf < kNKF; ++nf)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = fast_exp2(sc[nf][r]);
+                        sc[nf][r] = p;
+                        if constexpr (!ONES) sum += p;
+                    }
+            }
+            if constexpr (!ONES) l[rb] += quad_sum(sum);
+        };
+
         // Narrow heads (the fragments of a whole tile fit the register file): software pipeline, below.  Wide heads keep the
         // phase-by-phase form — resident fragments and the look-ahead accumulators would spill there.
         constexpr bool RES = 4 * KS + 2 * DF <= 22 && RB * DF <= 12;
@@ -220,64 +294,23 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restr
                     for (int kk = 0; kk < kNKF / 2; ++kk)
                         vf[df][kk] = vt_frag(Vc, df, kk);
             }
-            auto scores = [&](int rb, f32x4 (&sc)[kNKF]) {  // Sᵀ = K·Qᵀ for one 16-row block
+            // Sᵀ = K·Qᵀ − m for one 16-row block: the accumulators START at −m (0 while the row has no reference maximum yet)
+            auto scores = [&](int rb, f32x4 (&sc)[kNKF]) {
+                const float base = m[rb] == -INFINITY ? 0.f : -m[rb];
     #pragma unroll
                 for (int nf = 0; nf < kNKF; ++nf) {
-                    sc[nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    sc[nf] = f32x4{base, base, base, base};
     #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) sc[nf] = Mma<T>::k32(kfrag(nf, ks), qf[rb][ks], sc[nf]);
                 }
             };
-            f32x4 s_cur[kNKF], s_nxt[RES ? kNKF : 1];
-            if constexpr (RES) scores(0, s_cur);
+            f32x4 sbuf[2][kNKF];  // ping-pong: block rb lives in sbuf[rb & 1] (rb is a compile-time constant below)
+            scores(0, sbuf[0]);
     #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
-                if constexpr (RES) {
-                    if (rb + 1 < RB) scores(rb + 1, s_nxt);
-                } else {
-                    scores(rb, s_cur);  // no look-ahead where its 16 extra accumulator registers would spill
-                }
-                // ---- online softmax, one query row per lane (raw scores stay unscaled: exp2(s·c − m) is one fma + v_exp) ----
-                if constexpr (RAGGED) {  // keys past Tk never win the max and get probability 0
-                    const int key_base = kt * kTile + lq * 4;
-    #pragma unroll
-                    for (int nf = 0; nf < kNKF; ++nf)
-    #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (key_base + nf * 16 + r >= Tk) s_cur[nf][r] = -INFINITY;
-                }
-                float mt = -INFINITY;
-    #pragma unroll
-                for (int nf = 0; nf < kNKF; ++nf)
-    #pragma unroll
-                    for (int r = 0; r < 4; ++r) mt = fmaxf(mt, s_cur[nf][r]);
-                mt = quad_max(mt);
-                // Lazy rescaling: the reference maximum only moves when some row of the wave outgrows it by more than 2^8 —
-                // after the first tiles almost never — so the exp2 of the correction and the DF·4 accumulator multiplies are
-                // skipped on most tiles.  Probabilities then reach at most 2^8 (exact in fp32, far inside the 16-bit operand's
-                // range); O = o / l and LSE = m + log2 l do not depend on which m was used.
-                const float m_cand = fmaxf(m[rb], mt * scale_log2e);  // scale > 0: max commutes with the scaling
-                if (__any(m_cand > m[rb] + 8.f)) {                     // first tile: m = −inf
-                    // only the rows that outgrew their reference move it (the others multiply by exp2(0) = 1): a row's result
-                    // never depends on which other rows share its wave
-                    const float m_upd = m_cand > m[rb] + 8.f ? m_cand : m[rb];
-                    const float alpha = fast_exp2(m[rb] - m_upd);
-                    m[rb] = m_upd;
-                    l[rb] *= alpha;
-    #pragma unroll
-                    for (int df = 0; df < DF; ++df) o[rb][df] *= alpha;
-                }
-                const float m_ref = m[rb];
-                float sum = 0.f;
-    #pragma unroll
-                for (int nf = 0; nf < kNKF; ++nf)
-    #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float p = fast_exp2(fmaf(s_cur[nf][r], scale_log2e, -m_ref));
-                        s_cur[nf][r] = p;
-                        if constexpr (!ONES) sum += p;
-                    }
-                if constexpr (!ONES) l[rb] += quad_sum(sum);
+                f32x4 (&s_cur)[kNKF] = sbuf[rb & 1];
+                if (rb + 1 < RB) scores(rb + 1, sbuf[(rb + 1) & 1]);
+                softmax_block(rb, s_cur, kt);
                 // ---- Oᵀ += Vᵀ·Pᵀ for this block ----------------------------------------------------------------------
     #pragma unroll
                 for (int kk = 0; kk < kNKF / 2; ++kk) {
@@ -285,20 +318,16 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restr
     #pragma unroll
                     for (int df = 0; df < DF; ++df) o[rb][df] = Mma<T>::k32(vfrag(df, kk), pf, o[rb][df]);
                 }
-                if constexpr (RES) {
-                    if (rb + 1 < RB) {
-    #pragma unroll
-                        for (int nf = 0; nf < kNKF; ++nf) s_cur[nf] = s_nxt[nf];
-                    }
-                }
             }
         } else {
-            // ---- Sᵀ = K·Qᵀ: every K fragment read once, used for all RB row blocks -----------------
+            // ---- Sᵀ = K·Qᵀ − m: every K fragment read once, used for all RB row blocks; the chains start at −m -----------------
             f32x4 s[RB][kNKF];
     #pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
+            for (int rb = 0; rb < RB; ++rb) {
+                const float base = m[rb] == -INFINITY ? 0.f : -m[rb];
     #pragma unroll
-                for (int nf = 0; nf < kNKF; ++nf) s[rb][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int nf = 0; nf < kNKF; ++nf) s[rb][nf] = f32x4{base, base, base, base};
+            }
     #pragma unroll
             for (int nf = 0; nf < kNKF; ++nf)
     #pragma unroll
@@ -307,52 +336,10 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restr
     #pragma unroll
                     for (int rb = 0; rb < RB; ++rb) s[rb][nf] = Mma<T>::k32(kf, qf[rb][ks], s[rb][nf]);
                 }
-            // ---- online softmax, one query row per lane (raw scores stay unscaled: exp2(s·c − m) is one fma + v_exp) ----
-            if constexpr (RAGGED) {  // keys past Tk never win the max and get probability 0
-                const int key_base = kt * kTile + lq * 4;
-    #pragma unroll
-                for (int rb = 0; rb < RB; ++rb)
-    #pragma unroll
-                    for (int nf = 0; nf < kNKF; ++nf)
-    #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (key_base + nf * 16 + r >= Tk) s[rb][nf][r] = -INFINITY;
-            }
             F8 pf[RB][kNKF / 2];
     #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
-                float mt = -INFINITY;
-    #pragma unroll
-                for (int nf = 0; nf < kNKF; ++nf)
-    #pragma unroll
-                    for (int r = 0; r < 4; ++r) mt = fmaxf(mt, s[rb][nf][r]);
-                mt = quad_max(mt);
-                // Lazy rescaling: the reference maximum only moves when some row of the wave outgrows it by more than 2^8 —
-                // after the first tiles almost never — so the exp2 of the correction and the DF·4 accumulator multiplies are
-                // skipped on most tiles.  Probabilities then reach at most 2^8 (exact in fp32, far inside the 16-bit operand's
-                // range); O = o / l and LSE = m + log2 l do not depend on which m was used.
-                const float m_cand = fmaxf(m[rb], mt * scale_log2e);  // scale > 0: max commutes with the scaling
-                if (__any(m_cand > m[rb] + 8.f)) {                     // first tile: m = −inf
-                    // only the rows that outgrew their reference move it (the others multiply by exp2(0) = 1): a row's result
-                    // never depends on which other rows share its wave
-                    const float m_upd = m_cand > m[rb] + 8.f ? m_cand : m[rb];
-                    const float alpha = fast_exp2(m[rb] - m_upd);
-                    m[rb] = m_upd;
-                    l[rb] *= alpha;
-    #pragma unroll
-                    for (int df = 0; df < DF; ++df) o[rb][df] *= alpha;
-                }
-                const float m_ref = m[rb];
-                float sum = 0.f;
-    #pragma unroll
-                for (int nf = 0; nf < kNKF; ++nf)
-    #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float p = fast_exp2(fmaf(s[rb][nf][r], scale_log2e, -m_ref));
-                        s[rb][nf][r] = p;
-                        if constexpr (!ONES) sum += p;
-                    }
-                if constexpr (!ONES) l[rb] += quad_sum(sum);
+                softmax_block(rb, s[rb], kt);
     #pragma unroll
                 for (int kk = 0; kk < kNKF / 2; ++kk) pf[rb][kk] = pair_frag<T>(s[rb][2 * kk], s[rb][2 * kk + 1]);
             }
@@ -442,6 +429,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const T* __restri
         const bool valid = t < Tq;
         const int64_t roff = ((int64_t)b * Tq + t) * HD + h * d;
         load_row_frags<T, KS>(Q + ((int64_t)b * Tq + t) * ldq + h * d, Q, valid, d, lq, qf[rb]);
+        prescale_frags<T, KS>(qf[rb], scale_log2e);  // (Q only feeds the scores here: S comes out in the exp2 domain)
         load_row_frags<T, KS>(dO + roff, dO, valid, d, lq, gf[rb]);
         lse[rb] = valid ? LSE[(int64_t)bh * Tq + t] : INFINITY;  // +inf: probability 0 for rows past the end
         // Δ = Σ_c dO·O of the row (the softmax correction), computed here from the dO fragments the kernel holds anyway and
@@ -475,11 +463,16 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const T* __restri
         const T* Vc = Vs + cur * S::K_HALFS;
         if (kt + 1 < n_tiles) stage.load(Kh + (int64_t)(kt + 1) * kTile * ldq, Vh + (int64_t)(kt + 1) * kTile * ldq, Tk - (kt + 1) * kTile);
 
+        // row constants as the initial accumulators: S′ = c·q·k − LSE and dP′ = dO·v − Δ leave the matrix pipe ready, so that
+        // p = exp2(S′) and dS = p·dP′ cost one v_exp_f32 and one multiply per score (no fma, no subtraction)
         f32x4 s[RB][kNKF], dp[RB][kNKF];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int nf = 0; nf < kNKF; ++nf) s[rb][nf] = dp[rb][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int nf = 0; nf < kNKF; ++nf) {
+                s[rb][nf] = f32x4{-lse[rb], -lse[rb], -lse[rb], -lse[rb]};
+                dp[rb][nf] = f32x4{-delta[rb], -delta[rb], -delta[rb], -delta[rb]};
+            }
 #pragma unroll
         for (int nf = 0; nf < kNKF; ++nf)
 #pragma unroll
@@ -501,11 +494,11 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const T* __restri
             for (int nf = 0; nf < kNKF; ++nf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float p = fast_exp2(fmaf(s[rb][nf][r], scale_log2e, -lse[rb]));
+                    float p = fast_exp2(s[rb][nf][r]);
                     if constexpr (RAGGED) {
                         if (key_base + nf * 16 + r >= Tk) p = 0.f;
                     }
-                    s[rb][nf][r] = p * (dp[rb][nf][r] - delta[rb]);  // the 1/√d factor is applied once, on the way out
+                    s[rb][nf][r] = p * dp[rb][nf][r];  // the 1/√d factor is applied once, on the way out
                 }
 #pragma unroll
             for (int kk = 0; kk < kNKF / 2; ++kk) dsf[rb][kk] = pair_frag<T>(s[rb][2 * kk], s[rb][2 * kk + 1]);
@@ -602,6 +595,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
     for (int nf = 0; nf < NKW; ++nf) {
         const int key = key0 + nf * 16 + l15;
         load_row_frags<T, KS>(Kh + (int64_t)key * ldq, Kh, key < Tk, d, lq, kfr[nf]);
+        prescale_frags<T, KS>(kfr[nf], scale_log2e);  // (these K fragments only feed the scores: dK contracts dS with Q)
         load_row_frags<T, KS>(Vh + (int64_t)key * ldq, Vh, key < Tk, d, lq, vfr[nf]);
     }
     f32x4 dk[NKW][DF], dv[NKW][DF];  // lane = head-dim column l15 of fragment df; keys nf*16 + lq*4 + r
@@ -651,7 +645,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
                     const f32x4 del4 = *reinterpret_cast<const f32x4*>(dc + r0 + hb * 16 + lq * 4);
 #pragma unroll
                     for (int nf = 0; nf < NKW; ++nf) {
-                        f32x4 s2 = f32x4{0.f, 0.f, 0.f, 0.f}, dp2 = f32x4{0.f, 0.f, 0.f, 0.f};
+                        f32x4 s2 = -lse4, dp2 = -del4;  // row constants as the initial accumulators (see the dQ kernel)
 #pragma unroll
                         for (int ks = 0; ks < KS; ++ks) {
                             s2 = Mma<T>::k32(qa[ks], kfr[nf][ks], s2);  // D[q][key]: lane = key, rows lq*4 + r
@@ -659,10 +653,10 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
                         }
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            float p = fast_exp2(fmaf(s2[r], scale_log2e, -lse4[r]));
+                            float p = fast_exp2(s2[r]);
                             if (keys_ragged && key0 + nf * 16 + l15 >= Tk) p = 0.f;
                             pa[nf][hb * 4 + r] = from_f32<T>(p);
-                            dsa[nf][hb * 4 + r] = from_f32<T>(p * (dp2[r] - del4[r]));  // 1/√d goes onto dK at the end
+                            dsa[nf][hb * 4 + r] = from_f32<T>(p * dp2[r]);  // 1/√d goes onto dK at the end
                         }
                     }
                 }
@@ -701,7 +695,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
                 }
 #pragma unroll
                 for (int nf = 0; nf < NKW; ++nf) {
-                    f32x4 s2 = f32x4{0.f, 0.f, 0.f, 0.f}, dp2 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    f32x4 s2 = -lse4, dp2 = -del4;  // row constants as the initial accumulators (see the dQ kernel)
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
                         s2 = Mma<T>::k32(qa[ks], kfr[nf][ks], s2);    // D[q][key]: lane = key, rows lq*4 + r
@@ -710,10 +704,10 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
                     T pa[4], dsa[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float p = fast_exp2(fmaf(s2[r], scale_log2e, -lse4[r]));
+                        float p = fast_exp2(s2[r]);
                         if (keys_ragged && key0 + nf * 16 + l15 >= Tk) p = 0.f;
                         pa[r] = from_f32<T>(p);
-                        dsa[r] = from_f32<T>(p * (dp2[r] - del4[r]));  // 1/√d goes onto dK at the end
+                        dsa[r] = from_f32<T>(p * dp2[r]);  // 1/√d goes onto dK at the end
                     }
 #pragma unroll
                     for (int df = 0; df < DF; ++df) {

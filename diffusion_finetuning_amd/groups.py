@@ -170,6 +170,8 @@ def _dropin_ready(group, cdtype) -> bool:
     if reg is None:
         return False
     for l in group.layers:
+        if "_dfa_grad_sink" in l.__dict__:
+            return False  # the member joined a trainer's slab since: its gradients belong there (the slab's own groups, if any)
         if _auto_sink_for(l.lora_down.weight, l.lora_up.weight) is None:
             return False
     return reg.ensure(group.layers, cdtype)

@@ -84,6 +84,10 @@ class LoraSlab:
             self.model_ranges.append((start, end))
         if not self.layers:
             raise ValueError("No lora injected.")
+        from .attention import _attach_dropin_groups
+
+        for model in models:  # groups the attention switch built for a slab-less trainer: this slab brings its own (or none)
+            _attach_dropin_groups(model, False)
         device = self.layers[0].lora_up.weight.device
         if device.type != "cuda":
             raise RuntimeError("LoraSlab: the model must be on the HIP device")
