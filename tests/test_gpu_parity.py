@@ -1033,7 +1033,9 @@ def test_flash_attention_core_against_float64_reference(relerr, dtype):
         got = flash_attention(qd, kd, vd, H)
         got.backward(go.to(DEV))
         for name, a, b in (("o", got, want), ("dq", qd.grad, qr.grad), ("dk", kd.grad, kr.grad), ("dv", vd.grad, vr.grad)):
-            assert relerr(a, b) < tol, (name, (B, Tq, Tk, H, d), relerr(a, b))
+            # (a gradient that is EXACTLY zero in float64 — one key: softmax ≡ 1, dS ≡ 0 — has no relative error; the kernels
+            #  form dP − Δ inside the MFMA chain since round 4 and may leave the smallest f16 subnormal there: absolute bound)
+            assert relerr(a, b) < tol or float((a.double().cpu() - b).abs().max()) < 1e-6, (name, (B, Tq, Tk, H, d), relerr(a, b))
     # inference form (no gradient requested): no log-sum-exp buffer, same output
     with torch.no_grad():
         assert torch.equal(flash_attention(qd, kd, vd, H), got)
