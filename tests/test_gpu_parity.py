@@ -1436,3 +1436,27 @@ def test_seeded_step_draws_timesteps_below_t_multiplier(tiny_unet_factory, monke
         assert seen and all(n == 50 and tmax < 50 for n, tmax in seen), seen
         trainer.step(lat.to(DEV), None, None, ctx.to(DEV), seed=9)
         assert seen[-1][0] == 1000
+
+
+def test_autograd_grad_callers_get_gradients_with_deferral_off(tiny_unet_factory, relerr, monkeypatch):
+    """`torch.autograd.grad(loss, lora_params)` is not a `.backward()`: the drop-in sink defers the factor gradients to the end
+    of a backward PASS and hands them to `.grad`, so such a caller sees None for them (ops._AutoSink docstring).  The documented
+    switch — DFA_DEFER_GRADS=0 — restores per-layer launches that RETURN the gradients: they must equal the deferred ones."""
+    unet = tiny_unet_factory(seed=2).to(DEV)
+    params, _ = dfa.inject_trainable_lora(unet, r=4)
+    plist = list(itertools.chain(*params))
+    _warm(plist, 5, 0.02)
+    lat, noise, ts, ctx = orc.synthetic_batch(0, 2, 8, 6, 32)
+
+    def loss():
+        return dfa.ddpm_mse_loss(unet(lat.to(DEV), ts.to(DEV), ctx.to(DEV)).sample, noise.to(DEV))
+
+    loss().backward()
+    deferred = [p.grad.clone() for p in plist]
+    for p in plist:
+        p.grad = None
+    monkeypatch.setenv("DFA_DEFER_GRADS", "0")
+    grads = torch.autograd.grad(loss(), plist)
+    assert all(p.grad is None for p in plist)
+    for g, d in zip(grads, deferred):
+        assert relerr(g, d) < 1e-5, relerr(g, d)

@@ -102,8 +102,9 @@ def grads():
     for i,(M,K,N) in enumerate(layers):
         dy = buf(M,N)[i%3]; x = buf(M,K)[(i+1)%3]; t = torch.randn(M,r,device=dev); u = torch.randn(M,r,device=dev)
         keep += [t,u]
-        probs.append(nat.grad_problem(dy,0,N,N,t,0,r,r,[partials.data_ptr()+4*off],r,False,stride,M,1.0))
-        probs.append(nat.grad_problem(x,0,K,K,u,0,r,r,[partials.data_ptr()+4*(off+N*r)],r,True,stride,M,1.0))
+        only = os.environ.get("GB_GRADS_ONLY", "")  # "gB": the dYᵀ·T halves alone, "gA": the Uᵀ·X halves alone
+        if only != "gA": probs.append(nat.grad_problem(dy,0,N,N,t,0,r,r,[partials.data_ptr()+4*off],r,False,stride,M,1.0))
+        if only != "gB": probs.append(nat.grad_problem(x,0,K,K,u,0,r,r,[partials.data_ptr()+4*(off+N*r)],r,True,stride,M,1.0))
         ranges.append([off, r*(K+N), nat.grad_row_blocks(M), 0]); off += r*(K+N); nbytes += 2.0*M*(K+N)
     table = torch.tensor(ranges,dtype=torch.int64).to(dev)
     d0 = torch.device(dev,0)

@@ -24,9 +24,10 @@ def short(name):
     t = re.search(r"I(DF16_|DF16b|f)(?:Li(\d+)E)?(?:Li(\d+)E)?(?:Lb(\d)E)?(?:Lb(\d)E)?", name)
     out = m.group(1) + ("<" + ",".join(x for x in t.groups() if x) + ">" if t else "")
     # the fused GEMM's remaining template arguments: ring depth, the GEGLU-gate form (0 none, 1 forward, 2 backward), split-K
-    g = re.search(r"lora_gemm_kernelI(?:DF16_|DF16b|f)Li\d+ELi\d+ELb\dELi(\d+)ELi\d+ELi\d+ELi(\d+)E(?:Lb(\d)E)?", name)
+    g = re.search(r"lora_gemm_kernelI(?:DF16_|DF16b|f)Li\d+ELi\d+ELb\dELi(\d+)ELi\d+ELi\d+ELi(\d+)E(?:Lb(\d)E)?(?:Li(\d+)E)?", name)
     if g:
-        out = out[:-1] + f",s{g.group(1)},g{g.group(2)}" + (",splitk" if g.group(3) == "1" else "") + ">"
+        out = out[:-1] + f",s{g.group(1)},g{g.group(2)}" + (",splitk" if g.group(3) == "1" else "") + \
+            (f",kp{g.group(4)}" if g.group(4) not in (None, "1") else "") + ">"
     return out
 
 
