@@ -123,6 +123,20 @@ __device__ __forceinline__ float quad_sum(float x) {
     return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
+// Workgroup → (block along x, batch·head) with the blocks of ONE (batch, head) kept on ONE XCD.  The hardware deals consecutive
+// workgroup ids (x fastest) round-robin to the eight XCDs, so with the plain (blockIdx.x, blockIdx.y) mapping the 16 row blocks of
+// a head are spread over all eight L2s and every one of them fetches that head's K and V (forward, dQ) or Q and dO (dK/dV): 4.5×
+// the algorithmic bytes at 4096 tokens (PMC, round 4).  Here XCD x owns a contiguous run of (batch·head, block) pairs — the same
+// bijective remap as the fused GEMM's tiles — so a head's streamed operands are fetched by one L2.
+__device__ __forceinline__ void xcd_block(int& bx, int& bh) {
+    const unsigned nx = gridDim.x, total = gridDim.x * gridDim.y;
+    const unsigned id = blockIdx.x + nx * blockIdx.y;
+    const unsigned q = total >> 3, rem = total & 7, xcd = id & 7, slot = id >> 3;
+    const unsigned n = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
+    bh = (int)(n / nx);
+    bx = (int)(n - (unsigned)bh * nx);
+}
+
 // max of the 16 scores a lane holds for one row block, as a tree of three-input maxima (v_max3_f32): 8 instructions instead of
 // the 16-long chain the scalar loop compiles to
 __device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
@@ -160,7 +174,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restr
     T* Ks = reinterpret_cast<T*>(smem);            // [2][kTile][KROW]
     T* Vs = Ks + 2 * S::K_HALFS;                    // [2][kTile][KROW]
 
-    const int bh = blockIdx.y;
+    int bx, bh;
+    xcd_block(bx, bh);
     const int b = bh / H, h = bh - b * H;
     const int64_t HD = (int64_t)H * d;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -170,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restr
     const T* Kh = K + (int64_t)b * Tk * ldq + h * d;
     const T* Vh = V + (int64_t)b * Tk * ldq + h * d;
 
-    const int row0 = blockIdx.x * (64 * RB) + wave * (16 * RB);  // first query row of this wave
+    const int row0 = bx * (64 * RB) + wave * (16 * RB);  // first query row of this wave
     F8 qf[RB][KS];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
@@ -411,14 +426,15 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const T* __restri
     T* Ks = reinterpret_cast<T*>(smem);   // [2][kTile][KROW]
     T* Vs = Ks + 2 * S::K_HALFS;           // [2][kTile][KROW]
 
-    const int bh = blockIdx.y;
+    int bx, bh;
+    xcd_block(bx, bh);
     const int b = bh / H, h = bh - b * H;
     const int64_t HD = (int64_t)H * d;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     const T* Kh = K + (int64_t)b * Tk * ldq + h * d;
     const T* Vh = V + (int64_t)b * Tk * ldq + h * d;
-    const int row0 = blockIdx.x * (64 * RB) + wave * (16 * RB);
+    const int row0 = bx * (64 * RB) + wave * (16 * RB);
 
     F8 qf[RB][KS], gf[RB][KS];
     float lse[RB], delta[RB];
@@ -576,7 +592,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
     float* lse_s = reinterpret_cast<float*>(Gs + 2 * S::K_HALFS);  // [2][64]
     float* delta_s = lse_s + 2 * 64;                               // [2][64]
 
-    const int bh = blockIdx.y;
+    int bx, bh;
+    xcd_block(bx, bh);
     const int b = bh / H, h = bh - b * H;
     const int64_t HD = (int64_t)H * d;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -587,7 +604,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
     const T* Vh = V + (int64_t)b * Tk * ldq + h * d;
     const float* lse_h = LSE + (int64_t)bh * Tq;
     const float* delta_h = Delta + (int64_t)bh * Tq;
-    const int key0 = blockIdx.x * (64 * NKW) + wave * (16 * NKW);  // first key of this wave
+    const int key0 = bx * (64 * NKW) + wave * (16 * NKW);  // first key of this wave
 
     // the wave's keys as second MFMA operands (lane = key row, 8 head-dim values), kept for the whole kernel
     F8 kfr[NKW][KS], vfr[NKW][KS];
