@@ -415,7 +415,7 @@ def run_workload(args, cfg_id, rank, world, device, dist, profile=True):
         for mode in (False, graph_mode):
             trainer.capture_graph = mode
             run_step(0)
-        chk = trainer.slab.params[: trainer.slab.numel].double()
+        chk = trainer.slab.params.double()  # LoRA region AND the dense tail (config 5: the token table)
         sig = torch.stack([chk.sum(), (chk * torch.arange(1, chk.numel() + 1, device=device, dtype=torch.float64)).sum()])
         lo, hi = sig.clone(), sig.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
