@@ -500,9 +500,7 @@ class TokenTable:
         self.grad = slab.grads[a:b].view(self.V, self.D)
         self.out_dtype = out_dtype
         self._pending = []
-        if "forward" not in self.module.__dict__:
-            self.module.__dict__["_dfa_original_forward"] = self.module.forward
-        self.module.forward = functools.partial(self._forward, self.module)
+        self.module.forward = functools.partial(self._forward, self.module)  # (instance attribute: the class is untouched)
 
     def _forward(self, module, input_ids):
         dt = torch.get_autocast_dtype("cuda") if (torch.is_autocast_enabled("cuda") and self.out_dtype != torch.float32) \
@@ -524,11 +522,6 @@ class TokenTable:
                 dist.all_gather(all_rows, rows, group=pg)
                 ids, rows = torch.cat(all_ids), torch.cat(all_rows)
             nat.embed_rows_bwd(rows, ids, self.grad, accumulate=k > 0)
-
-    def detach(self):
-        orig = self.module.__dict__.pop("_dfa_original_forward", None)
-        if orig is not None:
-            del self.module.forward
 
 
 class LoraTrainer:
