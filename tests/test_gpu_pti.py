@@ -270,3 +270,35 @@ def test_full_size_cfg5_pti_step_with_token_embeddings_vs_cpu_oracle(relerr):
     assert t_agree > 0.95, t_agree
     # rows of absent tokens: decoupled weight decay only, bit-for-bit AdamW semantics on a zero gradient
     assert relerr(got_table[~used][:2000], want_table[~used][:2000]) < 1e-6
+
+
+def test_new_entry_points_edge_cases():
+    """Empty inputs, out-of-range ids and the combinations the library declines (include/lora_hip.h: lora_gemm_parts,
+    embed_rows_*): no launch for empty work, LORA_E_UNSUPPORTED (→ False: the caller runs the layers one by one) for f32 and
+    for a part-wise backward that is not three parts, LORA_E_BADARG for a width that does not split evenly."""
+    table = torch.arange(12, dtype=torch.float32, device=DEV).view(3, 4)
+    empty = torch.empty(0, dtype=torch.int64, device=DEV)
+    assert nat.embed_rows_fwd(table, empty, torch.float16).shape == (0, 4)
+    grad = torch.full((3, 4), 7.0, device=DEV)
+    nat.embed_rows_bwd(torch.empty(0, 4, dtype=torch.float16, device=DEV), empty, grad)
+    assert torch.equal(grad, torch.full_like(grad, 7.0))
+    ids = torch.tensor([5, -1, 1], device=DEV)                       # forward clamps, backward skips what is out of range
+    assert torch.equal(nat.embed_rows_fwd(table, ids, torch.float32), table[torch.tensor([2, 0, 1], device=DEV)])
+    nat.embed_rows_bwd(torch.ones(3, 4, device=DEV), ids, grad)
+    assert torch.equal(grad[1], torch.ones(4, device=DEV)) and torch.equal(grad[0], torch.full((4,), 7.0, device=DEV))
+
+    K = N = 64
+    x = torch.randn(16, K, device=DEV).half()
+    w = torch.randn(3 * N, K, device=DEV).half()
+    fa = torch.zeros(3 * 16 * K, device=DEV).half()
+    qb = torch.zeros(3 * N * 16, device=DEV).half()
+    y = torch.empty(16, 3 * N, device=DEV).half()
+    t = torch.empty(16, 24, device=DEV)
+    assert nat.lora_gemm_parts(x[:0], w, None, fa, qb, y[:0], t[:0], 24, 0, K, 3 * N, 8, 3, False, 1.0)   # M = 0: nothing to do
+    assert nat.lora_gemm_parts(x, w, None, fa, qb, y, t, 24, 16, K, 3 * N, 8, 3, False, 1.0)
+    assert torch.allclose(y.float(), x.float() @ w.float().t(), atol=2e-2, rtol=2e-3)                      # zero factors: the base GEMM
+    assert not nat.lora_gemm_parts(x.float(), w.float(), None, fa.float(), qb.float(), y.float(), t, 24, 16, K, 3 * N, 8, 3,
+                                   False, 1.0)                                                              # f32: unsupported
+    assert not nat.lora_gemm_parts(x, w[:2 * N], None, fa, qb, y, t, 24, 16, K, 2 * N, 8, 2, True, 1.0)     # part-wise backward: 3 parts only
+    with pytest.raises(RuntimeError):
+        nat.lora_gemm_parts(x, w, None, fa, qb, y, t, 24, 16, K, 3 * N - 8, 8, 3, False, 1.0)              # width not divisible
