@@ -262,21 +262,16 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const T* __restr
     #pragma unroll
                 for (int nf = 0; nf < kNKF; ++nf)
     #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float p = fast_exp2(sc[nf][r] - shift);
-                        sc[nf][r] = p;
-                        if constexpr (!ONES) sum += p;
-                    }
-            } else {
-    #pragma unroll
-                for (int nf = 0; nf < kNKF; ++nf)
-    #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float p = fast_exp2(sc[nf][r]);
-                        sc[nf][r] = p;
-                        if constexpr (!ONES) sum += p;
-                    }
+                    for (int r = 0; r < 4; ++r) sc[nf][r] -= shift;  // (only on the tiles where some row of the wave moved)
             }
+    #pragma unroll
+            for (int nf = 0; nf < kNKF; ++nf)
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = fast_exp2(sc[nf][r]);
+                    sc[nf][r] = p;
+                    if constexpr (!ONES) sum += p;
+                }
             if constexpr (!ONES) l[rb] += quad_sum(sum);
         };
 
