@@ -13,7 +13,7 @@ _LIB_PATH = os.environ.get("DFA_LIB_PATH") or os.path.join(os.path.dirname(os.pa
 _lib = None
 _lock = threading.Lock()
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 PROF_KINDS = 17
 
 _DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
@@ -80,7 +80,8 @@ SIGNATURES = {
     "ddpm_noise_prologue": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, ctypes.c_uint64, ctypes.c_uint64,
                                    _i32, _i32, _vp]),
     "embed_rows_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i32, _vp]),
-    "embed_rows_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i32, _i32, _vp]),
+    "embed_rows_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _i32, _vp]),
+    "lora_adamw_rows": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
     "geglu_linear_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "geglu_gate_fwd": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "geglu_gate_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
@@ -552,13 +553,25 @@ def embed_rows_fwd(table, ids, out_dtype: torch.dtype):
     return out.view(*ids.shape, D)
 
 
-def embed_rows_bwd(d_rows, ids, grad_table, accumulate: bool = False) -> None:
-    """grad_table[t] (+)= Σ of the rows d_rows[p] with ids[p] == t, positions in ascending order (deterministic)."""
-    _require_device(d_rows, ids, grad_table)
+def embed_rows_bwd(d_rows, ids, grad_table, accumulate: bool = False, active=None) -> None:
+    """grad_table[t] (+)= Σ of the rows d_rows[p] with ids[p] == t, positions in ascending order (deterministic);
+    active [V] uint8 (optional): set to 1 for every token that occurs."""
+    _require_device(d_rows, ids, grad_table, active)
     V, D = grad_table.shape
     assert d_rows.is_contiguous() and ids.is_contiguous() and d_rows.numel() == ids.numel() * D
-    _check(lib().embed_rows_bwd(_ptr(d_rows), _ptr(ids), _ptr(grad_table), ids.numel(), D, V, dtype_code(d_rows.dtype),
-                                int(accumulate), _stream(d_rows)), "embed_rows_bwd")
+    assert active is None or (active.dtype == torch.uint8 and active.numel() == V)
+    _check(lib().embed_rows_bwd(_ptr(d_rows), _ptr(ids), _ptr(grad_table), _ptr(active), ids.numel(), D, V,
+                                dtype_code(d_rows.dtype), int(accumulate), _stream(d_rows)), "embed_rows_bwd")
+
+
+def lora_adamw_rows(param, grad, exp_avg, exp_avg_sq, active, norm_in, grad_mul, max_norm, lr, beta1, beta2, eps,
+                    weight_decay, step: int) -> None:
+    """AdamW over a [V, D] table whose rows outside `active` never had a gradient (include/lora_hip.h: lora_adamw_rows)."""
+    _require_device(param, grad, exp_avg, exp_avg_sq, active, norm_in)
+    V, D = param.shape
+    _check(lib().lora_adamw_rows(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(active), V, D, _ptr(norm_in),
+                                 float(grad_mul), float(max_norm), float(lr), float(beta1), float(beta2), float(eps),
+                                 float(weight_decay), int(step), _stream(param)), "lora_adamw_rows")
 
 
 def geglu_gate_fwd(y2):

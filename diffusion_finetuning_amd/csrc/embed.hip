@@ -31,14 +31,15 @@ __global__ __launch_bounds__(256) void embed_rows_fwd_kernel(const float* __rest
 // of that token in ascending position order (fp32) and stores (or accumulates onto) the table-gradient row.
 template <typename T>
 __global__ __launch_bounds__(256) void embed_rows_bwd_kernel(const T* __restrict__ dE, const int64_t* __restrict__ ids,
-                                                              float* __restrict__ grad, int64_t n, int D, int64_t V,
-                                                              int accumulate) {
+                                                              float* __restrict__ grad, unsigned char* __restrict__ active,
+                                                              int64_t n, int D, int64_t V, int accumulate) {
     const int64_t p = blockIdx.x;
     const int64_t id = ids[p];
     if (id < 0 || id >= V) return;  // (block-uniform)
     int earlier = 0;
     for (int64_t q = threadIdx.x; q < p; q += 256) earlier |= ids[q] == id ? 1 : 0;
     if (__syncthreads_or(earlier)) return;
+    if (active != nullptr && threadIdx.x == 0) active[id] = 1;  // the row has (had) a gradient: lora_adamw_rows gives it the full update
     for (int c = threadIdx.x; c < D; c += 256) {
         float acc = accumulate ? grad[id * D + c] : 0.f;
         for (int64_t q = p; q < n; ++q)
@@ -67,17 +68,17 @@ extern "C" int embed_rows_fwd(const float* table, const int64_t* ids, void* out,
     return LORA_OK;
 }
 
-extern "C" int embed_rows_bwd(const void* dE, const int64_t* ids, float* grad_table, int64_t n, int D, int64_t V, int dtype,
-                              int accumulate, void* stream) {
+extern "C" int embed_rows_bwd(const void* dE, const int64_t* ids, float* grad_table, unsigned char* active, int64_t n, int D,
+                              int64_t V, int dtype, int accumulate, void* stream) {
     if (n < 0 || D < 1 || V < 1) return LORA_E_BADARG;
     if (n == 0) return LORA_OK;
     if (!dE || !ids || !grad_table) return LORA_E_BADARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)n);
     switch (dtype) {
-        case LORA_F32: hipLaunchKernelGGL(embed_rows_bwd_kernel<float>, grid, dim3(256), 0, s, static_cast<const float*>(dE), ids, grad_table, n, D, V, accumulate); break;
-        case LORA_F16: hipLaunchKernelGGL(embed_rows_bwd_kernel<half_t>, grid, dim3(256), 0, s, static_cast<const half_t*>(dE), ids, grad_table, n, D, V, accumulate); break;
-        case LORA_BF16: hipLaunchKernelGGL(embed_rows_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, static_cast<const bf16_t*>(dE), ids, grad_table, n, D, V, accumulate); break;
+        case LORA_F32: hipLaunchKernelGGL(embed_rows_bwd_kernel<float>, grid, dim3(256), 0, s, static_cast<const float*>(dE), ids, grad_table, active, n, D, V, accumulate); break;
+        case LORA_F16: hipLaunchKernelGGL(embed_rows_bwd_kernel<half_t>, grid, dim3(256), 0, s, static_cast<const half_t*>(dE), ids, grad_table, active, n, D, V, accumulate); break;
+        case LORA_BF16: hipLaunchKernelGGL(embed_rows_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, static_cast<const bf16_t*>(dE), ids, grad_table, active, n, D, V, accumulate); break;
         default: return LORA_E_BADARG;
     }
     LORA_LAUNCH_CHECK();

@@ -344,6 +344,12 @@ class FusedClipAdamW:
             a, b = g["range"]
             if b <= a:
                 continue
+            if g.get("rows") is not None:  # a table of which few rows ever get a gradient (TokenTable): same result, less traffic
+                V, D, active = g["rows"]
+                nat.lora_adamw_rows(s.params[a:b].view(V, D), s.grads[a:b].view(V, D), self.exp_avg[a:b].view(V, D),
+                                    self.exp_avg_sq[a:b].view(V, D), active, self.norm, grad_mul, self.max_grad_norm, g["lr"],
+                                    self.betas[0], self.betas[1], self.eps, g.get("weight_decay", 1e-2), 0)
+                continue
             nat.lora_adamw_step(s.params[a:b], s.grads[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], self.norm,
                                 grad_mul, self.max_grad_norm, g["lr"], self.betas[0], self.betas[1], self.eps,
                                 g.get("weight_decay", 1e-2), 0)
@@ -499,6 +505,7 @@ class TokenTable:
         a, b = self.range
         self.grad = slab.grads[a:b].view(self.V, self.D)
         self.out_dtype = out_dtype
+        self.active = torch.zeros(self.V, dtype=torch.uint8, device=w.device)  # rows that ever had a gradient (lora_adamw_rows)
         self._pending = []
         self.module.forward = functools.partial(self._forward, self.module)  # (instance attribute: the class is untouched)
 
@@ -521,7 +528,7 @@ class TokenTable:
                 dist.all_gather(all_ids, ids, group=pg)
                 dist.all_gather(all_rows, rows, group=pg)
                 ids, rows = torch.cat(all_ids), torch.cat(all_rows)
-            nat.embed_rows_bwd(rows, ids, self.grad, accumulate=k > 0)
+            nat.embed_rows_bwd(rows, ids, self.grad, accumulate=k > 0, active=self.active)
 
 
 class LoraTrainer:
@@ -568,6 +575,7 @@ class LoraTrainer:
         if train_emb:
             te_dtype = next((p.dtype for n_, p in text_encoder.named_parameters() if p is not emb.weight), torch.float32)
             self.token_table = TokenTable(self.slab, text_encoder, 0, te_dtype)
+            self.opt.groups[-1]["rows"] = (self.token_table.V, self.token_table.D, self.token_table.active)
         initial = float(loss_scale) if loss_scale is not None else (1024.0 if self.dtype == torch.float16 else 1.0)
         self.scaler = LossScaler(initial, self.GROWTH_INTERVAL)
         self._warned_overflow = False

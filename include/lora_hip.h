@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LORA_HIP_ABI_VERSION 6
+#define LORA_HIP_ABI_VERSION 7
 
 enum lora_dtype { LORA_F32 = 0, LORA_F16 = 1, LORA_BF16 = 2 };
 
@@ -371,11 +371,19 @@ int attn_merge_heads_strided(const void* src, void* dst, int B, int N, int H, in
  *   embed_rows_fwd : out[p, :] = table[ids[p], :] cast to out_dtype, p < n (ids int64; out of range ids are clamped).
  *   embed_rows_bwd : grad_table[t, :] (+)= Σ_{p : ids[p] == t} dE[p, :] for every token t that occurs, the positions added in
  *                    ascending order by ONE owner workgroup (torch's scatter uses atomics: run-to-run sum order).  Rows of tokens
- *                    that do not occur are not touched.  dE in `dtype`; accumulate = 0 overwrites the rows that occur.
+ *                    that do not occur are not touched.  dE in `dtype`; accumulate = 0 overwrites the rows that occur; active[t] = 1
+ *                    for every token that occurs (when given).
  */
 int embed_rows_fwd(const float* table, const int64_t* ids, void* out, int64_t n, int D, int64_t V, int out_dtype, void* stream);
-int embed_rows_bwd(const void* dE, const int64_t* ids, float* grad_table, int64_t n, int D, int64_t V, int dtype,
-                   int accumulate, void* stream);
+int embed_rows_bwd(const void* dE, const int64_t* ids, float* grad_table, unsigned char* active /* nullable: [V] */, int64_t n,
+                   int D, int64_t V, int dtype, int accumulate, void* stream);
+/* torch.optim.AdamW (`lora_adamw_step`'s arithmetic, same norm / skip / step-count inputs) over a [V, D] table of which only the
+ * rows flagged in `active` (set by embed_rows_bwd, never cleared) have ever had a gradient: those get the full update, every
+ * other row p ← p·(1 − lr·wd) — bit-identical to the dense update (g = m = v = 0 there), at a third of its traffic.
+ * Reference: the token table as an AdamW group, cli_lora_pti.py:706-738, stepped at :451. */
+int lora_adamw_rows(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const unsigned char* active, int64_t V,
+                    int D, const float* norm_in, float grad_mul, float max_norm, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int step, void* stream);
 
 /*
  * Short-context attention core  O = softmax(Q·Kᵀ·scale)·V  per head, for at most 128 keys: the cross-attention

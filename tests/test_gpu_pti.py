@@ -302,3 +302,38 @@ def test_new_entry_points_edge_cases():
     assert not nat.lora_gemm_parts(x, w[:2 * N], None, fa, qb, y, t, 24, 16, K, 2 * N, 8, 2, True, 1.0)     # part-wise backward: 3 parts only
     with pytest.raises(RuntimeError):
         nat.lora_gemm_parts(x, w, None, fa, qb, y, t, 24, 16, K, 3 * N - 8, 8, 3, False, 1.0)              # width not divisible
+
+
+def test_row_aware_adamw_equals_the_dense_update_bit_for_bit():
+    """lora_adamw_rows — full AdamW on the rows that ever had a gradient, p·(1 − lr·wd) on the others — against lora_adamw_step
+    over the whole table (torch.optim.AdamW's arithmetic, pinned elsewhere): for rows with g = m = v = 0 the dense update IS the
+    pure decay, so the two must agree BIT FOR BIT — parameters and both moments — over several steps, including a skipped
+    (overflowed) one and rows that were touched earlier but get no gradient now."""
+    g = torch.Generator().manual_seed(9)
+    V, D = 300, 64
+    p0 = torch.randn(V, D, generator=g).to(DEV)
+    state = [dict(p=p0.clone(), m=torch.zeros(V, D, device=DEV), v=torch.zeros(V, D, device=DEV)) for _ in range(2)]
+    active = torch.zeros(V, dtype=torch.uint8, device=DEV)
+    norm = [torch.zeros(4, device=DEV) for _ in range(2)]
+    for step in range(5):
+        ids = torch.randint(0, V, (40,), generator=g).to(DEV)
+        rows = torch.randn(40, D, generator=g).to(DEV)
+        if step == 2:
+            rows[3, 5] = float("inf")  # an overflowed step: skipped by both, the rows it touched still count as active
+        grads = [torch.zeros(V, D, device=DEV) for _ in range(2)]
+        nat.embed_rows_bwd(rows, ids, grads[0], active=None)
+        nat.embed_rows_bwd(rows, ids, grads[1], active=active)
+        assert torch.equal(grads[0], grads[1])
+        for k in range(2):
+            nat.lora_grad_sqnorm(grads[k].view(-1), 1.0, norm[k])
+        nat.lora_adamw_step(state[0]["p"].view(-1), grads[0].view(-1), state[0]["m"].view(-1), state[0]["v"].view(-1), norm[0],
+                            1.0, 1.0, 5e-3, 0.9, 0.999, 1e-8, 1e-3, 0)
+        nat.lora_adamw_rows(state[1]["p"], grads[1], state[1]["m"], state[1]["v"], active, norm[1], 1.0, 1.0, 5e-3, 0.9, 0.999, 1e-8,
+                            1e-3, 0)
+        for key in ("p", "m", "v"):
+            assert torch.equal(state[0][key], state[1][key]), (step, key)
+    assert 0 < int(active.sum()) < V and torch.equal(norm[0], norm[1])
+    assert float(norm[0][3]) == 1.0 and float(norm[0][2]) == 4.0  # one skipped, four applied steps
+    untouched = active == 0
+    assert torch.equal(state[1]["m"][untouched], torch.zeros_like(state[1]["m"][untouched]))
+    assert not torch.equal(state[1]["p"][untouched], p0[untouched])  # ... and they did decay
