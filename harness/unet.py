@@ -205,10 +205,7 @@ class Transformer2DModel(nn.Module):
             for blk in self.transformer_blocks:
                 x = blk(x, context)
             x = F.linear(x, self.proj_out.weight.view(c, c), self.proj_out.bias)
-            x = x.view(b, h, w, c).permute(0, 3, 1, 2)
-            if res.is_contiguous(memory_format=torch.channels_last) and not res.is_contiguous():
-                return x + res  # channels-last run (bench.py --channels-last): the token layout IS the NHWC tensor, no copy
-            return x.contiguous() + res
+            return x.view(b, h, w, c).permute(0, 3, 1, 2).contiguous() + res
         if self.linear_projection:
             x = self.proj_in(x.permute(0, 2, 3, 1).reshape(b, h * w, c))
         else:
