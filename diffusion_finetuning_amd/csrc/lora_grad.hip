@@ -2,7 +2,8 @@
 //     gB[N,r] = s·dYᵀ·T        gA[r,K] = s·Uᵀ·X          (T = X·Aᵀ, U = dY·B, both [M,r] fp32)
 // — the autograd of lora_diffusion/lora.py:49-50 restricted to the parameters that
 // lora.py:179-180 mark trainable.  Both are  G[c,j] = s·Σ_m S[m,c]·P[m,j]  with a streamed
-// operand S ∈ {dY, X} read exactly once, so this is an HBM-streaming kernel:
+// operand S ∈ {dY, X} read exactly once, so this is an HBM-streaming kernel.  16-bit operands take the matrix-core form
+// (lora_grad_mfma_kernel below); fp32 operands the VALU form:
 //   - a thread owns one 16-byte column chunk (8 halfs / 4 floats) and walks rows, several rows per trip so
 //     that independent loads are in flight; r×VEC fp32 accumulators stay in VGPRs; the P row is a broadcast load;
 //   - 256 threads cover ⌊256/CL⌋ rows per pass when the strip is narrower than the workgroup; the row
@@ -20,7 +21,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "common.h"
+#include "attn_common.h"
 
 namespace {
 
@@ -169,6 +170,158 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(const GradBatch p) {
     }
 }
 
+// The same reduction on the matrix cores, for 16-bit operands:  G[j, c] = Σ_m P[m, j]·S[m, c]  is an MFMA with the ROW index as
+// its contraction — first operand P (16 rank columns, zero-padded), second operand a 16-column fragment of S.  At rank 16
+// the VALU form above spends 128 FMAs per 16-byte chunk and is instruction-bound at ≈ 2 TB/s; here a 32-row × 16-column
+// fragment costs two MFMAs whatever the rank, and the kernel streams.
+//   - P is fp32: staged per 256-row chunk as an exact hi + lo pair of 16-bit values (the split lora_gemm.hip's rank
+//     epilogue uses), already in operand order, so a lane's eight contraction values are one 16-byte LDS read;
+//   - S goes global → registers → a wave-private LDS tile (32 rows × 64 columns) and comes back through the transposing
+//     read (ds_read_b64_tr_b16), which delivers exactly the second operand's layout; no workgroup barrier on that path —
+//     LDS operations of one wave complete in order — and the next step's rows are in flight while this one is multiplied;
+//   - a wave owns 64 columns of the strip for the whole row block: no cross-wave reduction, 16 accumulator registers.
+// Work decomposition (items, strips, row blocks, partial layout) is the VALU kernel's, so the fold is unchanged.
+constexpr int kTileLd = 64 + 8;  // elements per row of a wave's S tile (144 B: the transposing reads stay conflict-free)
+template <typename T>
+__global__ __launch_bounds__(256) void lora_grad_mfma_kernel(const GradBatch p) {
+    using F8 = typename Mma<T>::F8;
+    __shared__ __attribute__((aligned(16))) T sPh[kChunkRows * 16];  // [32-row group][j][lq][8 rows in operand order]
+    __shared__ __attribute__((aligned(16))) T sPl[kChunkRows * 16];
+    __shared__ __attribute__((aligned(16))) T sS[4][32 * kTileLd];
+
+    int it = 0;
+    for (int i = 1; i < p.n; ++i) it += ((int)blockIdx.x >= p.first_block[i]) ? 1 : 0;
+    it = __builtin_amdgcn_readfirstlane(it);
+    const GradItem& q = p.item[it];
+    const int local = blockIdx.x - p.first_block[it];
+    const int strip = local % q.strips;
+    const int rb = local / q.strips;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int c0 = strip * q.CL * 8;
+    const int stripW = min(q.CL * 8, q.C - c0);
+    const int cw = wave * 64;                      // this wave's first column inside the strip
+    const bool wave_on = cw < stripW;              // wave-uniform
+    const int r = q.r;
+
+    const int64_t m_begin = (int64_t)rb * q.rows_per_block;
+    int64_t m_end = m_begin + q.rows_per_block;
+    if (m_end > q.M) m_end = q.M;
+    const int n_rows = (int)(m_end - m_begin);
+    const int n_steps = (n_rows + 31) / 32;
+
+    // lane → four 16-byte pieces of the 32 × 64 tile: piece lane + 64·i is row (lane>>3) + 8·i, columns (lane&7)·8 …
+    // columns past the strip are read from its last chunk (their products land in outputs nobody stores)
+    const int prow = lane >> 3;
+    const int pcol = min(cw + (lane & 7) * 8, stripW - 8);
+    const T* S = static_cast<const T*>(q.S) + m_begin * q.s_stride + c0 + (wave_on ? pcol : 0);
+    T* tile = sS[wave];
+    T* tile_w = tile + prow * kTileLd + (lane & 7) * 8;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    typedef unsigned raw4 __attribute__((ext_vector_type(4)));  // 16 bytes, register-resident
+    // two steps of rows in flight (register sets a / b) while a third is multiplied
+    raw4 a0, a1, a2, a3, b0, b1, b2, b3;
+#define GRAD_LOAD_STEP(x, s_)                                                                                        \
+    do {                                                                                                             \
+        const int rbase_ = (s_) * 32 + prow; /* rows past the block: clamped, their P is zero */                     \
+        x##0 = *reinterpret_cast<const raw4*>(S + (int64_t)min(rbase_, n_rows - 1) * q.s_stride);                    \
+        x##1 = *reinterpret_cast<const raw4*>(S + (int64_t)min(rbase_ + 8, n_rows - 1) * q.s_stride);                \
+        x##2 = *reinterpret_cast<const raw4*>(S + (int64_t)min(rbase_ + 16, n_rows - 1) * q.s_stride);               \
+        x##3 = *reinterpret_cast<const raw4*>(S + (int64_t)min(rbase_ + 24, n_rows - 1) * q.s_stride);               \
+    } while (0)
+#define GRAD_STEP(x, s_)                                                                                             \
+    do {                                                                                                             \
+        const raw4 c0_ = x##0, c1_ = x##1, c2_ = x##2, c3_ = x##3;                                                   \
+        if ((s_) + 2 < n_steps) GRAD_LOAD_STEP(x, (s_) + 2);                                                         \
+        *reinterpret_cast<raw4*>(tile_w) = c0_;                                                                      \
+        *reinterpret_cast<raw4*>(tile_w + 8 * kTileLd) = c1_;                                                        \
+        *reinterpret_cast<raw4*>(tile_w + 16 * kTileLd) = c2_;                                                       \
+        *reinterpret_cast<raw4*>(tile_w + 24 * kTileLd) = c3_;                                                       \
+        const int at_ = ((((s_) & 7) * 16 + l15) * 4 + lq) << 3;                                                     \
+        const F8 ph_ = *reinterpret_cast<const F8*>(sPh + at_);                                                      \
+        const F8 pl_ = *reinterpret_cast<const F8*>(sPl + at_);                                                      \
+        _Pragma("unroll") for (int f = 0; f < 4; ++f) {                                                              \
+            const F8 sf_ = tr_pair<T>(lds_tr_block(tile + f * 16, kTileLd, lane),                                    \
+                                      lds_tr_block(tile + 16 * kTileLd + f * 16, kTileLd, lane));                    \
+            acc[f] = Mma<T>::k32(ph_, sf_, acc[f]);                                                                  \
+            acc[f] = Mma<T>::k32(pl_, sf_, acc[f]);                                                                  \
+        }                                                                                                            \
+    } while (0)
+    a0 = a1 = a2 = a3 = b0 = b1 = b2 = b3 = raw4{0u, 0u, 0u, 0u};
+    if (wave_on && n_steps > 0) GRAD_LOAD_STEP(a, 0);
+    if (wave_on && n_steps > 1) GRAD_LOAD_STEP(b, 1);
+
+    for (int s = 0; s < n_steps; s += 2) {
+        if ((s & 7) == 0) {  // the P rows of the next 256: hi/lo pairs in operand order
+            __syncthreads();
+            const int base = s * 32;
+            // a thread builds two operand vectors: rank column j, the eight rows one lane group multiplies.  Loads are
+            // unconditional from clamped addresses (a load under a per-lane condition is waited for one by one)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int u = tid + 256 * k;
+                const int j = u & 15, slot = u >> 4;
+                const int row0 = base + (slot >> 2) * 32 + (slot & 3) * 4;
+                const float* src = q.P + m_begin * q.p_stride + (j < r ? j : 0);
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int row = row0 + (e & 3) + ((e >> 2) << 4);
+                    v[e] = src[(int64_t)min(row, n_rows - 1) * q.p_stride];
+                }
+                F8 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int row = row0 + (e & 3) + ((e >> 2) << 4);
+                    const float x = (row < n_rows && j < r) ? v[e] : 0.f;
+                    const T h = from_f32<T>(x);
+                    hi[e] = h;
+                    lo[e] = from_f32<T>(x - to_f32<T>(h));
+                }
+                const int at = (((slot >> 2) * 16 + j) * 4 + (slot & 3)) << 3;
+                *reinterpret_cast<F8*>(sPh + at) = hi;
+                *reinterpret_cast<F8*>(sPl + at) = lo;
+            }
+            __syncthreads();
+        }
+        if (wave_on) {
+            GRAD_STEP(a, s);
+            if (s + 1 < n_steps) GRAD_STEP(b, s + 1);
+        }
+    }
+
+#undef GRAD_STEP
+#undef GRAD_LOAD_STEP
+    // lane (l15, lq) of fragment f holds G[j = 4·lq + e][c = cw + 16·f + l15]
+    if (wave_on) {
+        const int64_t part_off = (int64_t)rb * q.part_stride;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int c = cw + f * 16 + l15;
+            if (c < stripW) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = lq * 4 + e;
+                    if (j < r) {
+                        const int grp = j / q.rg, jl = j - grp * q.rg;
+                        float* G = q.out[grp] + part_off;
+                        const float v = acc[f][e] * q.scale;
+                        if (q.out_kn)
+                            G[(int64_t)jl * q.C + c0 + c] = v;
+                        else
+                            G[(int64_t)(c0 + c) * q.rg + jl] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Unaligned / large-rank path: one thread per output element, serial over the row block.  Correct, not fast.
 struct GenericGrad {
     const void* S;
@@ -268,11 +421,27 @@ bool plan_item(GradItem& q, int nb) {
     return true;
 }
 
+// smallest rank class that goes to the matrix-core kernel (16-bit operands only).  All of them by default: on the 288
+// problems of an SD1.5 step (tools/gemm_bench.py --grads, GB_RANK) it takes 372 / 403 / 417 µs at rank 4 / 8 / 16 where
+// the VALU kernel takes 396 / 657 / 1626.  LORA_GRAD_MFMA=99 sends everything back to the VALU kernel (A/B knob).
+int mfma_min_rank() {
+    static const int v = [] { const char* e = getenv("LORA_GRAD_MFMA"); return e ? atoi(e) : 4; }();
+    return v;
+}
+
 template <typename T>
 int launch_batch(const GradBatch& b, int rp, hipStream_t stream) {
     constexpr int VEC = ElemTraits<T>::kVec;
     const int lds = 256 * 4 * VEC * 4 + kChunkRows * rp * 4;  // reduction image + the staged P rows
     const dim3 grid((unsigned)b.first_block[b.n]);
+    if constexpr (sizeof(T) == 2) {
+        if (rp >= mfma_min_rank()) {
+            const int id = rp == 4 ? PK_GRAD_R4 : (rp == 8 ? PK_GRAD_R8 : PK_GRAD_R16);
+            LORA_LAUNCH(id, (lora_grad_mfma_kernel<T>), grid, dim3(256), 0, stream, b);
+            LORA_LAUNCH_CHECK();
+            return LORA_OK;
+        }
+    }
     switch (rp) {
         case 4: LORA_LAUNCH(PK_GRAD_R4, (lora_grad_kernel<T, 4>), grid, dim3(256), lds, stream, b); break;
         case 8: LORA_LAUNCH(PK_GRAD_R8, (lora_grad_kernel<T, 8>), grid, dim3(256), lds, stream, b); break;

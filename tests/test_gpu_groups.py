@@ -79,6 +79,50 @@ def test_batched_factor_gradients_vs_float64(close, dtype):
     assert torch.equal(grads, grads2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_factor_gradients_matrix_core_edges(close, dtype):
+    """The 16-bit factor-gradient kernel (lora_grad_mfma_kernel: rows are the MFMA contraction) at the edges of its tiling:
+    strips narrower than one 16-column fragment, widths that are no multiple of 64 (a wave's share) or 16, row counts
+    around the 32-row step and the 256-row P chunk, one row, every rank 1..16, both output layouts, strided operands,
+    large-magnitude fp32 P (the hi + lo split) — against float64."""
+    g = torch.Generator().manual_seed(11)
+    Ms = [1, 31, 32, 33, 255, 257, 511, 513, 1500]
+    Cs = [8, 24, 72, 328, 264, 1288]
+    specs = []
+    for i in range(48):
+        r = i % 16 + 1
+        specs.append((Ms[i % len(Ms)], Cs[(i // 3) % len(Cs)], r, i % 2 == 0, i % 4 == 1))
+    off, offs = 0, []
+    for (M, C, r, kn, st) in specs:
+        offs.append(off)
+        off += r * C
+    stride = (off + 3) // 4 * 4
+    partials = torch.full((nat.GRAD_MAX_BLOCKS, stride), float("nan"), device=DEV)
+    problems, refs, keep, ranges = [], [], [], []
+    for (M, C, r, kn, st), o in zip(specs, offs):
+        wide = C + 40 if st else C
+        Sfull = torch.randn(M, wide, generator=g).to(dtype).to(DEV)
+        Pfull = (torch.randn(M, r + (4 if st else 0), generator=g) * (300.0 if r % 5 == 0 else 1.0)).to(DEV)
+        s_off, p_off = (8, 4) if st else (0, 0)
+        problems.append(nat.grad_problem(Sfull, s_off, wide, C, Pfull, p_off, Pfull.shape[1], r,
+                                         [partials.data_ptr() + 4 * o], r, kn, stride, M, 1.3))
+        keep.append((Sfull, Pfull))
+        refs.append(_ref_grad(Sfull[:, s_off:s_off + C], Pfull[:, p_off:p_off + r], 1.3))
+        ranges.append([o, r * C, nat.grad_row_blocks(M), 0])
+    nat.lora_grad_batched(problems, dtype, torch.device(DEV, 0))
+    grads = torch.zeros(stride, device=DEV)
+    table = torch.tensor(ranges, dtype=torch.int64).to(DEV)
+    nat.lora_fold_partials(table, len(ranges), max(r_[1] for r_ in ranges), partials, stride, grads, False)
+    torch.cuda.synchronize()
+    assert torch.isfinite(grads).all()
+    # operands are exact 16-bit values, P is split exactly for fp16 (22 bits) and to 16 bits for bf16; sums are fp32
+    tol = 2e-5 if dtype == torch.float16 else 6e-5
+    for (M, C, r, kn, st), o, ref in zip(specs, offs, refs):
+        got = grads[o:o + r * C]
+        got = got.view(r, C).t() if kn else got.view(C, r)
+        close(got, ref, tol, (M, C, r, kn, st))
+
+
 def test_pack_items_layouts():
     """lora_pack_items: per-layer [A16|At16], [Bt16|B16] and the block-diagonal q/k/v layout (rows = r, destinations
     offset, buffer zeroed once)."""

@@ -91,7 +91,7 @@ def grads():
     """All 288 factor-gradient problems of one SD1.5 cfg-2 step in one lora_grad_batched call (+ the fold)."""
     dtype = torch.float16
     layers = [(16384,320,320)]*30 + [(16384,320,2560)]*5 + [(308,768,320)]*10 + [(4096,640,640)]*30 + [(4096,640,5120)]*5 + [(308,768,640)]*10 + [(1024,1280,1280)]*30 + [(1024,1280,10240)]*5 + [(308,768,1280)]*12 + [(256,1280,1280)]*6 + [(256,1280,10240)]*1
-    r = 4
+    r = int(os.environ.get("GB_RANK", 4))
     total = sum(r*(K+N) for _,K,N in layers); stride = (total+3)//4*4
     partials = torch.empty(nat.GRAD_MAX_BLOCKS, stride, device=dev); grads_ = torch.zeros(stride, device=dev)
     cache = {}
