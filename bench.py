@@ -252,14 +252,28 @@ def conv_autotune(args) -> bool:
     """Caller side, not the hot path: the UNet's convolutions (stock MIOpen, ≈ 10 ms of the step) run with MIOpen's solver SEARCH
     on (`torch.backends.cudnn.benchmark`) instead of its immediate-mode heuristics — +1–3 % images/s on the headline.  A search
     costs ≈ 3 minutes per workload on a fresh box, so its RESULTS ship with the harness: `harness/miopen_db/*.ufdb.txt` is MIOpen's
-    own user find-db (text, keyed by problem and gfx950 / 256 CUs / MIOpen version), written by `bench.py` runs on the GPU box and
-    pointed to with MIOPEN_USER_DB_PATH; with it the priming step finds every solver without benchmarking.  If the db is absent, or
+    own user find-db (text, keyed by problem and gfx950 / 256 CUs / MIOpen version), written by `BENCH_MIOPEN_DB_INPLACE=1 bench.py`
+    runs on the GPU box and handed to MIOpen through MIOPEN_USER_DB_PATH (a private per-process copy); with it the priming step finds every solver without benchmarking.  If the db is absent, or
     a priming step shows that a search is running after all (run_workload), the setting is dropped."""
     import glob
 
     if args.no_conv_autotune or os.environ.get("BENCH_CONV_AUTOTUNE", "1") == "0" or not glob.glob(os.path.join(MIOPEN_DB, "*.ufdb.txt")):
         return False
-    os.environ.setdefault("MIOPEN_USER_DB_PATH", MIOPEN_DB)
+    if "MIOPEN_USER_DB_PATH" not in os.environ:
+        if os.environ.get("BENCH_MIOPEN_DB_INPLACE", "0") == "1":  # how the shipped records were written: the search's results land in the tree
+            path = MIOPEN_DB
+        else:
+            # a private copy per process (two small text files): N ranks do not queue on MIOpen's lock files, and a box whose MIOpen
+            # adds a record does not edit tracked files.  The drop-in child process inherits the variable and reads this copy.
+            import atexit
+            import shutil
+            import tempfile
+
+            path = tempfile.mkdtemp(prefix="dfa_miopen_db_")
+            for f in glob.glob(os.path.join(MIOPEN_DB, "*.txt")):
+                shutil.copy(f, path)
+            atexit.register(shutil.rmtree, path, ignore_errors=True)
+        os.environ["MIOPEN_USER_DB_PATH"] = path
     torch.backends.cudnn.benchmark = True
     return True
 

@@ -29,8 +29,8 @@ thread_local double tl_bytes = 0.0, tl_flops = 0.0;
 
 const char* const kKernelNames[LORA_PROF_KINDS] = {
     "lora_gemm_kernel<*, 128, 128|160, true>", "lora_gemm_kernel<*, 256, 128, true>", "lora_gemm_kernel<*, 64, 64|128|160, true>",
-    "lora_gemm_kernel<*, 128, 64, false>", "lora_gemm_kernel<*, 64, 64, false>", "lora_grad_kernel<*, 4>",
-    "lora_grad_kernel<*, 8>",              "lora_grad_kernel<*, 16>",             "ddpm_mse_kernel",
+    "lora_gemm_kernel<*, 128, 64, false>", "lora_gemm_kernel<*, 64, 64, false>", "lora_grad_{mfma_,}kernel, ranks <= 4",
+    "lora_grad_{mfma_,}kernel, ranks 5-8", "lora_grad_{mfma_,}kernel, ranks 9-16", "ddpm_mse_kernel",
     "other",
     "geglu_linear_bwd: lora_gemm_kernel<*, 128, 128, GATE=2> (frozen ff.net.2 backward GEMM + GEGLU gate backward)",
     "attn_flash_fwd_kernel", "attn_flash_dq_kernel", "attn_flash_dkdv_kernel", "attn_ctx_fwd_kernel",

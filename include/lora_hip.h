@@ -229,6 +229,8 @@ int lora_reduce_partials(const float* partials, int64_t part_stride, int n_block
  * row blocks of a table of slab ranges, each with its own block count:
  *     grads[off+i] (+)= Σ_{b < blocks} partials[b·part_stride + off + i],  ranges[k] = {off, len, blocks, 0}
  * (int64, DEVICE memory), max_len = the largest len.  Deterministic like lora_reduce_partials.
+ * Arithmetic: fp32 sums.  16-bit operands are multiplied on the matrix cores with the row index as the contraction; P
+ * enters as an exact hi + lo pair of 16-bit values (fp16: 22 significant bits of P, bf16: 16).  fp32 operands: VALU FMAs.
  */
 #define LORA_GRAD_MAX_BLOCKS 64
 typedef struct lora_grad_problem {
