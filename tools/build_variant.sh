@@ -4,4 +4,4 @@
 name=$1; shift
 cd "$(dirname "$0")/../diffusion_finetuning_amd/csrc" || exit 1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -shared -o ../lib/liblora_hip_$name.so \
-  lora_gemm.hip lora_grad.hip ddpm_loss.hip optim.hip sandwich.hip attn_ctx.hip attn_flash.hip prof.hip && echo built $name
+  lora_gemm.hip lora_grad.hip ddpm_loss.hip optim.hip sandwich.hip attn_ctx.hip attn_flash.hip embed.hip prof.hip && echo built $name
