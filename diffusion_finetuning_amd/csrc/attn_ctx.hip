@@ -24,6 +24,8 @@
 
 namespace {
 
+constexpr int kCtxSumFrags = 32;  // accumulator fragments per wave and phase of the backward's closing sum (4 × 32 KB of LDS)
+
 template <int KS, int DF, int NKF> struct CtxShape {
     static constexpr int DP = KS * 32;       // head dim padded for the Q·Kᵀ contraction
     static constexpr int DV = DF * 16;       // head dim padded as an MFMA output extent
@@ -174,8 +176,12 @@ __global__ __launch_bounds__(256) void attn_ctx_fwd_kernel(const T* __restrict__
     }
 }
 
+// two workgroups per CU where the accumulators leave room for it (heads of ≤ 48 and ≤ 96 keys: 36 fragments, 247 registers): the row loop is a chain of
+// dependent LDS round trips that one wave per SIMD cannot hide
+template <int KS, int DF, int NKF> constexpr int ctx_bwd_occupancy() { return (KS == 2 && DF == 3 && NKF == 6) ? 2 : 1; }
+
 template <typename T, int KS, int DF, int NKF>
-__global__ __launch_bounds__(256) void attn_ctx_bwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
+__global__ __launch_bounds__(256, (ctx_bwd_occupancy<KS, DF, NKF>())) void attn_ctx_bwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
                                                             const T* __restrict__ V, const T* __restrict__ dO,
                                                             T* __restrict__ dQ, float* __restrict__ part, int Tq,
                                                             int Tk, int H, int d, float scale, float scale_log2e,
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(256) void attn_ctx_bwd_kernel(const T* __restrict__
     T* Gw = Qw + 16 * S::KROW;                    //                            ... and of its dO rows
     T* Pw = Vs + S::NK * S::KROW + 4 * 2 * 16 * S::KROW + (threadIdx.x >> 6) * 2 * 16 * S::TROW;  // wave's P  [16][TROW]
     T* Sw = Pw + 16 * S::TROW;                                                                      // wave's dS [16][TROW]
-    float* red = reinterpret_cast<float*>(smem);  // overlay after the main loop: [2][NK][DV]
+    float* red = reinterpret_cast<float*>(smem);  // overlay after the main loop: the waves' accumulator images
 
     const int chunk = blockIdx.x % chunks;
     const int bh = blockIdx.x / chunks;
@@ -321,69 +327,72 @@ __global__ __launch_bounds__(256) void attn_ctx_bwd_kernel(const T* __restrict__
         }
     }
 
-    // ---- sum the four waves' dK/dV through LDS in wave order, then one fp32 partial per workgroup ----------
+    // ---- sum the four waves' dK/dV in wave order, one fp32 partial per workgroup --------------------------------------
+    // All four waves deposit a run of accumulator fragments in LDS at once (one image per wave, fragment order
+    // [fragment][lane][r], whole 16-byte accumulators), then all 256 threads add the four images — ((w0 + w1) + w2) + w3, the
+    // order of the former wave-after-wave rounds, so the partials are bit-identical — and store the sums straight to the
+    // global partial.  The wave-after-wave form had ONE wave per round reading, adding and re-writing the whole image with
+    // no free registers to batch the reads behind (the kernel holds ~500): 4.4 – 8.6 µs per launch, plus 2.3 – 5 µs for
+    // copying the finished image out; this form: two or three short phases in which every lane works.
     __syncthreads();  // staging buffers are dead
-    // LDS image in fragment order — [tensor][nf][df][lane][r] — so every lane moves whole 16-byte accumulators
-    for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
-            f32x4* rk = reinterpret_cast<f32x4*>(red) + lane;
-            f32x4* rv = rk + NKF * DF * 64;
-            if (w == 0) {
+    constexpr int F = 2 * NKF * DF;                  // fragments per wave: dk then dv
+    constexpr int PH = (F + kCtxSumFrags - 1) / kCtxSumFrags;
+    constexpr int CH = (F + PH - 1) / PH;            // fragments per phase (≤ kCtxSumFrags)
+    f32x4* img = reinterpret_cast<f32x4*>(red);      // [4 waves][CH][64]
+    float* out = part + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 2 * S::NK * S::DV;
 #pragma unroll
-                for (int nf = 0; nf < NKF; ++nf)
+    for (int ph = 0; ph < PH; ++ph) {
 #pragma unroll
-                    for (int df = 0; df < DF; ++df) {
-                        rk[(nf * DF + df) * 64] = dk[nf][df];
-                        rv[(nf * DF + df) * 64] = dv[nf][df];
-                    }
-            } else {
-#pragma unroll
-                for (int nf = 0; nf < NKF; ++nf)
-#pragma unroll
-                    for (int df = 0; df < DF; ++df) {
-                        dk[nf][df] += rk[(nf * DF + df) * 64];
-                        dv[nf][df] += rv[(nf * DF + df) * 64];
-                    }
-#pragma unroll
-                for (int nf = 0; nf < NKF; ++nf)
-#pragma unroll
-                    for (int df = 0; df < DF; ++df) {
-                        rk[(nf * DF + df) * 64] = dk[nf][df];
-                        rv[(nf * DF + df) * 64] = dv[nf][df];
-                    }
+        for (int fl = 0; fl < CH; ++fl) {
+            const int f = ph * CH + fl;  // compile-time after unrolling
+            if (f < F) {
+                const int ten = f / (NKF * DF), rem = f - ten * (NKF * DF);
+                img[(wave * CH + fl) * 64 + lane] = ten == 0 ? dk[rem / DF][rem % DF] : dv[rem / DF][rem % DF];
             }
         }
         __syncthreads();
+        const int n_here = (F - ph * CH < CH ? F - ph * CH : CH) * 64;
+        for (int e = threadIdx.x; e < n_here; e += 256) {
+            const f32x4 v = ((img[e] + img[CH * 64 + e]) + img[2 * CH * 64 + e]) + img[3 * CH * 64 + e];
+            *reinterpret_cast<f32x4*>(out + ((int64_t)(ph * CH) * 64 + e) * 4) = v;
+        }
+        if (ph + 1 < PH) __syncthreads();
     }
-    float* out = part + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 2 * S::NK * S::DV;
-    for (int idx = threadIdx.x * 4; idx < 2 * S::NK * S::DV; idx += 1024)
-        *reinterpret_cast<f32x4*>(out + idx) = *reinterpret_cast<const f32x4*>(red + idx);
 }
 
-// dK/dV [B, Tk, H·d] = Σ_chunk partials, summed in chunk order (deterministic), cast to T
+// dK/dV [B, Tk, H·d] = Σ_chunk partials, summed in chunk order (deterministic), cast to T.  A thread owns one 16-byte
+// accumulator of the partial image (fragment order [tensor][nf][df][lane][r]: four consecutive keys of one head-dim column),
+// so the partials — the bulk of the traffic — are read as whole coalesced lines; the four outputs go out as 2-byte stores
+// into the (small) [B, Tk, H·d] gradients.  (The first form walked the OUTPUT in memory order and gathered 4 bytes out of
+// every 16 of the partials: 7 – 9.5 µs per launch against 4 – 6 now.)
 template <typename T>
 __global__ __launch_bounds__(256) void attn_ctx_reduce_kernel(const float* __restrict__ part, T* __restrict__ dK,
                                                                T* __restrict__ dV, int B, int Tk, int H, int d,
                                                                int chunks, int slices, int NK, int DV, int64_t ld_dk) {
-    const int64_t total = (int64_t)B * Tk * H * d;
+    const int per_img = (NK * DV) >> 2;                 // f32x4 per tensor of one partial
+    const int64_t per_grp = 2 * (int64_t)per_img;       // ... per (batch, head, slice)
+    const int64_t total = (int64_t)B * H * slices * per_grp;
+    const int dfs = DV >> 4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int c = (int)(i % d);
-        const int h = (int)((i / d) % H);
-        const int key = (int)((i / ((int64_t)d * H)) % Tk);
-        const int b = (int)(i / ((int64_t)d * H * Tk));
-        // fragment order [nf][df][lane = lq*16 + l15][r]:  key = nf*16 + lq*4 + r,  c = df*16 + l15
-        const int sl = c / DV, cs = c - sl * DV;  // head-dim slice and column inside it
-        const int nf = key >> 4, lq = (key >> 2) & 3, r = key & 3, df = cs >> 4, l15 = cs & 15;
-        const float* p = part + (((int64_t)(b * H + h) * chunks) * slices + sl) * 2 * NK * DV +
-                         (((nf * (DV / 16) + df) * 64 + lq * 16 + l15) << 2) + r;
-        float sk = 0.f, sv = 0.f;
-        for (int ch = 0; ch < chunks; ++ch) {
-            sk += p[(int64_t)ch * slices * 2 * NK * DV];
-            sv += p[(int64_t)ch * slices * 2 * NK * DV + NK * DV];
-        }
-        const int64_t o = ((int64_t)b * Tk + key) * ld_dk + (int64_t)h * d + c;
-        dK[o] = from_f32<T>(sk);
-        dV[o] = from_f32<T>(sv);
+        const int64_t grp = i / per_grp;                // (b·H + h)·slices + sl
+        const int e = (int)(i - grp * per_grp);
+        const int ten = e >= per_img ? 1 : 0, f = e - ten * per_img;
+        const int lane = f & 63, frag = f >> 6;
+        const int nf = frag / dfs, df = frag - nf * dfs;
+        const int sl = (int)(grp % slices);
+        const int64_t bh = grp / slices;
+        const int h = (int)(bh % H), b = (int)(bh / H);
+        const int c = sl * DV + df * 16 + (lane & 15);
+        const int key0 = nf * 16 + (lane >> 4) * 4;
+        if (c >= d || key0 >= Tk) continue;
+        // partial of chunk ch of this group: ((bh·chunks + ch)·slices + sl)·2·NK·DV floats
+        const f32x4* p = reinterpret_cast<const f32x4*>(part + ((bh * chunks) * slices + sl) * 2 * (int64_t)NK * DV) + e;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ch = 0; ch < chunks; ++ch) acc += p[(int64_t)ch * slices * per_grp];
+        T* out = (ten ? dV : dK) + ((int64_t)b * Tk + key0) * ld_dk + (int64_t)h * d + c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (key0 + r < Tk) out[(int64_t)r * ld_dk] = from_f32<T>(acc[r]);
     }
 }
 
@@ -408,7 +417,11 @@ bool plan_ctx(int B, int Tq, int Tk, int H, int d, bool backward, CtxPlan* pl) {
     }
     pl->nkf = Tk <= 96 ? 6 : 8;
     // enough workgroups to fill 256 CUs, but few chunks: every chunk re-stages K/V (and writes a partial in backward)
-    const int want = (backward ? 256 : 512) / (B * H * pl->slices);
+    // backward: one workgroup per CU (the accumulators take most of the register file), two where the kernel is built for it
+    // (ctx_bwd_occupancy).  More chunks than that lose: every chunk re-stages K/V and writes a dK/dV partial
+    // (profiles/r04_ctx_attention_workgroup_sweep.log)
+    const int bwd_wgs = (pl->ks == 2 && pl->df == 3 && pl->nkf == 6) ? 512 : 256;
+    const int want = (backward ? bwd_wgs : 512) / (B * H * pl->slices);
     int chunks = want < 1 ? 1 : want;
     const int max_chunks = (Tq + 63) / 64;
     if (chunks > max_chunks) chunks = max_chunks;
@@ -426,7 +439,8 @@ template <int KS, int DF, int NKF> constexpr int fwd_lds() {
 template <int KS, int DF, int NKF> constexpr int bwd_lds() {
     using S = CtxShape<KS, DF, NKF>;
     constexpr int stage = (2 * S::NK * S::KROW + 4 * 2 * 16 * S::KROW + 4 * 2 * 16 * S::TROW) * 2;
-    constexpr int red = 2 * S::NK * S::DV * 4;
+    constexpr int F = 2 * NKF * DF, PH = (F + kCtxSumFrags - 1) / kCtxSumFrags, CH = (F + PH - 1) / PH;
+    constexpr int red = 4 * CH * 64 * 16;  // four waves' images of one phase of the closing sum
     return stage > red ? stage : red;
 }
 
@@ -478,7 +492,7 @@ int launch_ctx(const CtxArgs& a, const CtxPlan& pl, hipStream_t stream) {
                 a.Tk, a.H, a.d, a.scale, l2e, pl.rq, pl.chunks, a.ldk);
     lora_prof_set_work(0.0, 0.0);
     LORA_LAUNCH_CHECK();
-    const int64_t total = (int64_t)a.B * a.Tk * a.H * a.d;
+    const int64_t total = (int64_t)a.B * a.H * pl.slices * 2 * (NKF * 16) * (DF * 16) / 4;  // 16-byte accumulators of one partial set
     const unsigned blocks = (unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
     // (the ordered sum of the chunk partials: its time is charged to the backward's kind, it carries no algorithmic bytes)
     LORA_LAUNCH(PK_CTX_BWD, attn_ctx_reduce_kernel<T>, dim3(blocks), dim3(256), 0, stream, a.part, static_cast<T*>(a.dK),
