@@ -3,6 +3,9 @@
   python tools/summarize_profile.py trace <kernel_trace.csv> <warmup_steps> <out.csv>
       per-kernel stats of the TIMED region only (from the (warmup+1)-th add_noise dispatch on), so one-time
       MIOpen solver searches during warm-up do not pollute the table.
+  python tools/summarize_profile.py gaps <kernel_trace.csv> <warmup_steps>
+      idle time between consecutive dispatches of the timed region (wall of the region against the sum of kernel durations,
+      a histogram of the gaps and the kernels that the largest ones follow): what the replayed graph loses between nodes.
   python tools/summarize_profile.py pmc <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [<mfma_counter_collection.csv>]
       average FETCH_SIZE / WRITE_SIZE (KB) per dispatch for the hot-path kernels, and the corrected traffic
       (2·FETCH_SIZE + WRITE_SIZE)·1024 bytes (MI355X_MICROARCH.md §HBM: FETCH_SIZE reads ½ on gfx950); with a third
@@ -54,6 +57,42 @@ def trace(path, warmup, out):
                         f"{sum(v) / steps / 1e6:.3f}", f"{100 * sum(v) / total:.2f}"])
         w.writerow(["TOTAL (timed region, %d steps)" % steps, "", "", "", "", f"{total / steps / 1e6:.3f}", "100"])
     print(open(out).read())
+
+
+def gaps(path, warmup):
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    starts = [int(r["Start_Timestamp"]) for r in rows if _step_start(r["Kernel_Name"])]
+    t0 = starts[warmup]
+    steps = len(starts) - warmup
+    reg = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in rows if int(r["Start_Timestamp"]) >= t0]
+    # the region ends with the last dispatch of the last step; kernels may overlap (two queues): track the running end
+    busy = 0
+    idle = []
+    end = reg[0][0]
+    for (a, b, name), prev in zip(reg, [None] + reg[:-1]):
+        if a > end:
+            idle.append((a - end, prev[2] if prev else "", name))
+            busy += b - a
+        else:
+            busy += max(0, b - end)
+        end = max(end, b)
+    wall = end - reg[0][0]
+    tot_idle = sum(g for g, _, _ in idle)
+    print(f"timed region: {steps} steps, wall {wall / steps / 1e6:.3f} ms/step, GPU busy {busy / steps / 1e6:.3f} ms/step, "
+          f"idle between dispatches {tot_idle / steps / 1e6:.3f} ms/step ({100 * tot_idle / wall:.1f} %), "
+          f"{len(reg) / steps:.0f} dispatches/step, {len(idle) / steps:.0f} gaps/step")
+    edges = [0, 500, 1000, 2000, 4000, 8000, 16000, 10 ** 12]
+    for lo, hi in zip(edges, edges[1:]):
+        sel = [g for g, _, _ in idle if lo <= g < hi]
+        print(f"  gaps {lo / 1e3:5.1f} - {hi / 1e3 if hi < 10 ** 11 else float('inf'):5.1f} us: {len(sel) / steps:7.1f} per step, {sum(sel) / steps / 1e6:.3f} ms/step")
+    by = collections.defaultdict(lambda: [0, 0])
+    for g, prev, nxt in idle:
+        by[(prev[:60], nxt[:60])][0] += 1
+        by[(prev[:60], nxt[:60])][1] += g
+    print("  largest contributors (previous kernel -> next kernel):")
+    for (prev, nxt), (n, t) in sorted(by.items(), key=lambda kv: -kv[1][1])[:15]:
+        print(f"    {t / steps / 1e3:8.1f} us/step  {n / steps:6.1f} x  {t / n / 1e3:6.2f} us  {prev}  ->  {nxt}")
 
 
 def pmc(fetch, write, out, mfma=None):
@@ -112,5 +151,7 @@ if __name__ == "__main__":
         shapes(sys.argv[2], int(sys.argv[3]))
     elif sys.argv[1] == "trace":
         trace(sys.argv[2], int(sys.argv[3]), sys.argv[4])
+    elif sys.argv[1] == "gaps":
+        gaps(sys.argv[2], int(sys.argv[3]))
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else None)
