@@ -30,8 +30,12 @@ template <int KS, int DF, int NKF> struct CtxShape {
     static constexpr int DP = KS * 32;       // head dim padded for the Q·Kᵀ contraction
     static constexpr int DV = DF * 16;       // head dim padded as an MFMA output extent
     static constexpr int NK = NKF * 16;      // keys padded
-    static constexpr int KROW = DP + 8;      // LDS row strides (halfs), +16 B against bank conflicts
-    static constexpr int TROW = NK + 8;
+    // LDS row strides (halfs).  K/V/Q/dO tiles: +32 B — a stride ≡ 32 (mod 64) bytes is what makes the fragment reads
+    // (ds_read_b128, serviced in the lane groups {0–3,12–15,20–27}, …) and the transposing reads (two groups of 32 lanes)
+    // conflict-free on gfx950's 64 banks; +16 B made every one of them a 2-way conflict (attn_flash.hip, FlashShape).  P/dS
+    // tiles: +32 B halves their transposing reads' conflicts (3-way → 2-way: four 8-byte pieces 16 bytes apart per row).
+    static constexpr int KROW = DP + 16;
+    static constexpr int TROW = NK + 16;
 };
 
 // K (or V) of one (batch, head) → registers: thread owns chunks idx = tid + i*256 of the [NK][DP/8] chunk grid

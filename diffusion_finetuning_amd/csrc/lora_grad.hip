@@ -181,7 +181,13 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(const GradBatch p) {
 //     LDS operations of one wave complete in order — and the next step's rows are in flight while this one is multiplied;
 //   - a wave owns 64 columns of the strip for the whole row block: no cross-wave reduction, 16 accumulator registers.
 // Work decomposition (items, strips, row blocks, partial layout) is the VALU kernel's, so the fold is unchanged.
-constexpr int kTileLd = 64 + 8;  // elements per row of a wave's S tile (144 B: the transposing reads stay conflict-free)
+// elements per row of a wave's S tile: 160 B.  A row stride ≡ 32 (mod 64) bytes is what keeps ds_read_b64_tr_b16 (two groups
+// of 32 lanes over 64 banks) conflict-free on gfx950; 144 B made every transposing read a 2-way conflict (PMC, round 4)
+constexpr int kTileLd = 64 + 16;
+// the 16-byte slot of lane group lq inside rank column j's 64-byte record of the P image: ds_read_b128 is serviced in the
+// lane groups {0–3,12–15,20–27}, {4–11,16–19,28–31}, …, i.e. columns j and j ± 4, ± 8, ± 12 — which share their 16 banks —
+// meet in one group with two different lq; this XOR keeps their four slots distinct in every group
+__device__ __forceinline__ int p_slot(int j, int lq) { return lq ^ ((4 - (j >> 2)) & 3); }
 template <typename T>
 __global__ __launch_bounds__(256) void lora_grad_mfma_kernel(const GradBatch p) {
     using F8 = typename Mma<T>::F8;
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(256) void lora_grad_mfma_kernel(const GradBatch p) 
         *reinterpret_cast<raw4*>(tile_w + 8 * kTileLd) = c1_;                                                        \
         *reinterpret_cast<raw4*>(tile_w + 16 * kTileLd) = c2_;                                                       \
         *reinterpret_cast<raw4*>(tile_w + 24 * kTileLd) = c3_;                                                       \
-        const int at_ = ((((s_) & 7) * 16 + l15) * 4 + lq) << 3;                                                     \
+        const int at_ = ((((s_) & 7) * 16 + l15) * 4 + p_slot(l15, lq)) << 3;                                        \
         const F8 ph_ = *reinterpret_cast<const F8*>(sPh + at_);                                                      \
         const F8 pl_ = *reinterpret_cast<const F8*>(sPl + at_);                                                      \
         _Pragma("unroll") for (int f = 0; f < 4; ++f) {                                                              \
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(256) void lora_grad_mfma_kernel(const GradBatch p) 
                     hi[e] = h;
                     lo[e] = from_f32<T>(x - to_f32<T>(h));
                 }
-                const int at = (((slot >> 2) * 16 + j) * 4 + (slot & 3)) << 3;
+                const int at = (((slot >> 2) * 16 + j) * 4 + p_slot(j, slot & 3)) << 3;
                 *reinterpret_cast<F8*>(sPh + at) = hi;
                 *reinterpret_cast<F8*>(sPl + at) = lo;
             }
