@@ -54,7 +54,7 @@ def parse():
                     help="timed oracle steps of cpu_baseline.same_resolution (~3 s each on 16 cores; cfg1 always runs its 10)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --shared-gpu rehearses N ranks on one GPU")
     ap.add_argument("--shared-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
-    ap.add_argument("--stub-body", default=None, choices=["ok", "fail"],
+    ap.add_argument("--stub-body", default=None, choices=["ok", "fail", "diverge"],
                     help="test hook: ranks only rendezvous over gloo on the CPU and rank 0 prints a stub JSON line "
                          "('fail': rank 1 exits non-zero) — exercises the launcher without a GPU")
     return ap.parse_args()
@@ -93,22 +93,61 @@ def launch_ranks(n: int) -> int:
     return rc
 
 
+def replicas_identical(flat, dist, rank) -> bool:
+    """Two-word signature of a rank's trainable state (sum and index-weighted sum, float64), MIN- and MAX-reduced over the
+    ranks: equal on every rank, or some replica diverged (a missed collective, a different loss scale)."""
+    chk = flat.double()
+    sig = torch.stack([chk.sum(), (chk * torch.arange(1, chk.numel() + 1, device=chk.device, dtype=torch.float64)).sum()])
+    lo, hi = sig.clone(), sig.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if not torch.equal(lo, hi):
+        log(f"rank {rank}: LoRA slab differs across ranks after the rehearsal steps ({sig.tolist()} vs min {lo.tolist()} / "
+            f"max {hi.tolist()}) — aborting")
+        return False
+    return True
+
+
 def stub_body(args, rank, world):
-    """Launcher test body (CPU only): every rank joins a gloo group and contributes to one all-reduce; rank 0 prints a
-    line with the contract's keys.  'fail' makes rank 1 exit non-zero so the launcher's error propagation is visible."""
+    """Launcher rehearsal body (CPU only, gloo): the data-parallel skeleton of the real body without a GPU — every rank holds a
+    replica of a small slab, takes `steps` steps on its own shard with the REAL exchange (trainer.SlabExchange: one SUM
+    all-reduce of the gradient slab, 1/world folded into the update), then the ranks compare replica signatures exactly as
+    the real body does (exit code 4 on a divergence); rank 0 prints ONE line with the contract's keys, `config.rccl_ranks` /
+    `backend` as the process group reports them.  'fail' makes rank 1 exit non-zero (error propagation of the launcher);
+    'diverge' makes the last rank skip the exchange of one step."""
     import torch.distributed as dist
+
+    from diffusion_finetuning_amd.trainer import SlabExchange
 
     if args.stub_body == "fail" and rank == 1:
         sys.exit(3)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
+    g = torch.Generator().manual_seed(0)
+    slab = torch.randn(1024, generator=g)            # identical initial replicas (the real body broadcasts rank 0's)
+    grads = torch.zeros_like(slab)
+    ex = SlabExchange(grads, grads.numel(), None)
+    ex.single = True                                 # a recorded step's exchange: the whole slab in one all-reduce
+    for step in range(args.warmup + args.steps):
+        gs = torch.Generator().manual_seed(1000 * step + rank)   # every rank its own shard
+        grads.copy_(torch.randn(1024, generator=gs))
+        ex.arm()
+        if not (args.stub_body == "diverge" and rank == world - 1 and step == 1):
+            ex.finish()
+        elif world > 1:  # keep the collective sequence (nobody hangs), but train on something else
+            dist.all_reduce(grads.clone())
+        slab -= 1e-2 * grads / world
+    if world > 1 and not replicas_identical(slab, dist, rank):
+        sys.exit(4)
     t = torch.tensor([float(rank + 1)])
     if world > 1:
         dist.all_reduce(t)
     if rank == 0:
         print(json.dumps({"metric": "stub", "value": float(t.item()), "unit": "ranksum", "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "stub": True}), flush=True)
+                          "steps": args.steps, "warmup": args.warmup, "stub": True, "scaling": "weak",
+                          "config": {"parallelism": f"dp{world}", "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+                                     "backend": dist.get_backend() if world > 1 else None}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -459,14 +498,7 @@ def run_workload(args, cfg_id, rank, world, device, dist, profile=True):
         for mode in (False, graph_mode):
             trainer.capture_graph = mode
             run_step(0)
-        chk = trainer.slab.params.double()  # LoRA region AND the dense tail (config 5: the token table)
-        sig = torch.stack([chk.sum(), (chk * torch.arange(1, chk.numel() + 1, device=device, dtype=torch.float64)).sum()])
-        lo, hi = sig.clone(), sig.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        if not torch.equal(lo, hi):
-            log(f"rank {rank}: LoRA slab differs across ranks after the rehearsal steps ({sig.tolist()} vs min {lo.tolist()} / "
-                f"max {hi.tolist()}) — aborting")
+        if not replicas_identical(trainer.slab.params, dist, rank):  # LoRA region AND the dense tail (config 5: the token table)
             sys.exit(4)
     trainer.slab.params.copy_(snapshot[0]); trainer.opt.exp_avg.copy_(snapshot[1]); trainer.opt.exp_avg_sq.copy_(snapshot[2])
     trainer.opt.step_count = snapshot[3]

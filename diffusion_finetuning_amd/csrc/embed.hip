@@ -13,18 +13,24 @@ namespace {
 template <typename T>
 __global__ __launch_bounds__(256) void embed_rows_fwd_kernel(const float* __restrict__ table, const int64_t* __restrict__ ids,
                                                               T* __restrict__ out, int D, int64_t V) {
-    int64_t id = ids[blockIdx.x];
-    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
-    const float4* src = reinterpret_cast<const float4*>(table + id * D);
+    const int64_t id = ids[blockIdx.x];
     T* dst = out + (int64_t)blockIdx.x * D;
-    for (int c = threadIdx.x; c < D / 4; c += 256) {
+    if (id < 0 || id >= V) {
+        // An id outside the table (torch.nn.Embedding raises): the row is POISONED with NaN — the loss of the step is NaN, the
+        // optimizer's overflow check skips the update and the trainer warns — instead of silently training on another token's
+        // row; the backward kernel drops the same positions.  The binding layer validates ids on the host whenever it can.
+        const T nan = from_f32<T>(__builtin_nanf(""));
+        for (int c = threadIdx.x; c < D; c += 256) dst[c] = nan;
+        return;  // (block-uniform)
+    }
+    const float4* src = reinterpret_cast<const float4*>(table + id * D);
+    for (int c = threadIdx.x; c < D / 4; c += 256) {  // (D % 4 == 0: checked by the entry point)
         const float4 v = src[c];
         dst[4 * c + 0] = from_f32<T>(v.x);
         dst[4 * c + 1] = from_f32<T>(v.y);
         dst[4 * c + 2] = from_f32<T>(v.z);
         dst[4 * c + 3] = from_f32<T>(v.w);
     }
-    for (int c = (D / 4) * 4 + threadIdx.x; c < D; c += 256) dst[c] = from_f32<T>(table[id * D + c]);
 }
 
 // grid = positions.  Block p exits unless p is the FIRST position of its token; the owner adds the rows of every position

@@ -174,8 +174,14 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(const GradBatch p) {
 // its contraction — first operand P (16 rank columns, zero-padded), second operand a 16-column fragment of S.  At rank 16
 // the VALU form above spends 128 FMAs per 16-byte chunk and is instruction-bound at ≈ 2 TB/s; here a 32-row × 16-column
 // fragment costs two MFMAs whatever the rank, and the kernel streams.
-//   - P is fp32: staged per 256-row chunk as an exact hi + lo pair of 16-bit values (the split lora_gemm.hip's rank
-//     epilogue uses), already in operand order, so a lane's eight contraction values are one 16-byte LDS read;
+//   - P is fp32: staged per 256-row chunk as a hi + lo pair of 16-bit values (the split lora_gemm.hip's rank
+//     epilogue uses), already in operand order, so a lane's eight contraction values are one 16-byte LDS read.  fp16 has
+//     five exponent bits, so the pair is only exact in a window: below 2^-3 the lo part is subnormal, below 2^-14 the hi
+//     part is, above 65504 it is inf — and U = dY·B shrinks with the loss scale while T = X·Aᵀ is not scaled at all.  So
+//     for fp16 every rank column of P is multiplied by a power of two chosen per ROW BLOCK (its largest magnitude lands
+//     in [2^13, 2^14): a prologue pass over the block's P rows, L2-resident, they are shared by all strips) and the
+//     inverse goes into the final scale: 22 significant bits for the entries within 2^-17 of their column's maximum,
+//     degrading gracefully below, whatever the magnitude of P.  bf16 has fp32's exponent range and needs none of this;
 //   - S goes global → registers → a wave-private LDS tile (32 rows × 64 columns) and comes back through the transposing
 //     read (ds_read_b64_tr_b16), which delivers exactly the second operand's layout; no workgroup barrier on that path —
 //     LDS operations of one wave complete in order — and the next step's rows are in flight while this one is multiplied;
@@ -194,6 +200,9 @@ __global__ __launch_bounds__(256) void lora_grad_mfma_kernel(const GradBatch p) 
     __shared__ __attribute__((aligned(16))) T sPh[kChunkRows * 16];  // [32-row group][j][lq][8 rows in operand order]
     __shared__ __attribute__((aligned(16))) T sPl[kChunkRows * 16];
     __shared__ __attribute__((aligned(16))) T sS[4][32 * kTileLd];
+    __shared__ float sColMax[4][16];
+    __shared__ float sScale[2][16];  // [0][j]: 2^k of rank column j for this row block, [1][j]: 2^-k
+    constexpr bool kScaleP = sizeof(typename Mma<T>::F8) == 16 && std::is_same<T, half_t>::value;
 
     int it = 0;
     for (int i = 1; i < p.n; ++i) it += ((int)blockIdx.x >= p.first_block[i]) ? 1 : 0;
@@ -262,6 +271,26 @@ __global__ __launch_bounds__(256) void lora_grad_mfma_kernel(const GradBatch p) 
     if (wave_on && n_steps > 0) GRAD_LOAD_STEP(a, 0);
     if (wave_on && n_steps > 1) GRAD_LOAD_STEP(b, 1);
 
+    if (kScaleP) {  // per rank column: the power of two that centres this row block's P in fp16's exact hi + lo window
+        const int j = tid & 15;
+        const float* src = q.P + m_begin * q.p_stride + (j < r ? j : 0);
+        float mx = 0.f;
+        for (int row = tid >> 4; row < n_rows; row += 16) mx = fmaxf(mx, fabsf(src[(int64_t)row * q.p_stride]));
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (lane < 16) sColMax[wave][lane] = mx;
+        __syncthreads();
+        if (tid < 16) {
+            const float m4 = fmaxf(fmaxf(sColMax[0][tid], sColMax[1][tid]), fmaxf(sColMax[2][tid], sColMax[3][tid]));
+            int e = 0;
+            if (m4 > 0.f && m4 < __builtin_inff()) (void)frexpf(m4, &e);  // m4 < 2^e
+            const int k = max(-100, min(100, 14 - e));                    // (inf / nan in P: k = 14, the gradient comes out non-finite)
+            sScale[0][tid] = m4 > 0.f ? ldexpf(1.f, k) : 1.f;
+            sScale[1][tid] = m4 > 0.f ? ldexpf(1.f, -k) : 1.f;
+        }
+        // (published by the barrier that opens the first chunk's staging below)
+    }
+
     for (int s = 0; s < n_steps; s += 2) {
         if ((s & 7) == 0) {  // the P rows of the next 256: hi/lo pairs in operand order
             __syncthreads();
@@ -280,11 +309,12 @@ __global__ __launch_bounds__(256) void lora_grad_mfma_kernel(const GradBatch p) 
                     const int row = row0 + (e & 3) + ((e >> 2) << 4);
                     v[e] = src[(int64_t)min(row, n_rows - 1) * q.p_stride];
                 }
+                const float pscale = kScaleP ? sScale[0][j] : 1.f;
                 F8 hi, lo;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int row = row0 + (e & 3) + ((e >> 2) << 4);
-                    const float x = (row < n_rows && j < r) ? v[e] : 0.f;
+                    const float x = (row < n_rows && j < r) ? v[e] * pscale : 0.f;
                     const T h = from_f32<T>(x);
                     hi[e] = h;
                     lo[e] = from_f32<T>(x - to_f32<T>(h));
@@ -316,7 +346,7 @@ __global__ __launch_bounds__(256) void lora_grad_mfma_kernel(const GradBatch p) 
                     if (j < r) {
                         const int grp = j / q.rg, jl = j - grp * q.rg;
                         float* G = q.out[grp] + part_off;
-                        const float v = acc[f][e] * q.scale;
+                        const float v = acc[f][e] * (kScaleP ? q.scale * sScale[1][j] : q.scale);
                         if (q.out_kn)
                             G[(int64_t)jl * q.C + c0 + c] = v;
                         else

@@ -33,6 +33,51 @@ def ddpm_tables(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, de
     return acp.sqrt().to(device), (1.0 - acp).sqrt().to(device)
 
 
+SCHEDULER_NAMES = ("linear", "cosine", "cosine_with_restarts", "polynomial", "constant", "constant_with_warmup")
+
+
+def lr_lambda(name: str, num_warmup_steps: int = 0, num_training_steps: Optional[int] = None, lr_init: float = 1.0):
+    """λ(epoch): the factor the trainers' `get_scheduler(name, optimizer, num_warmup_steps, num_training_steps)` puts on every
+    param group's learning rate after `epoch` calls of `lr_scheduler.step()` (train_lora_dreambooth.py:737-743 with `--lr_scheduler`
+    choices :345-353, default "constant"; cli_lora_pti.py:746-751, default "linear" with 0 warm-up steps :534-535).  The function
+    is diffusers' (`diffusers.optimization`, a torch LambdaLR per name) and not part of the reference tree: the formulas are
+    restated from its published definitions — parity unpinned for them; the LambdaLR mechanics around them (λ(0) at
+    construction, one increment per step(), lr = base_lr·λ) are torch's and are what the fixture pins."""
+    w = int(num_warmup_steps)
+    if name not in SCHEDULER_NAMES:
+        raise ValueError(f"unknown lr_scheduler {name!r}; one of {SCHEDULER_NAMES}")
+    if name == "constant":
+        return lambda e: 1.0
+    if name == "constant_with_warmup":
+        return lambda e: float(e) / float(max(1.0, w)) if e < w else 1.0
+    if num_training_steps is None:
+        raise ValueError(f"{name} requires `num_training_steps`, please provide that argument.")
+    n = int(num_training_steps)
+    ramp = lambda e: float(e) / float(max(1, w))
+    if name == "linear":
+        return lambda e: ramp(e) if e < w else max(0.0, float(n - e) / float(max(1, n - w)))
+    if name == "cosine":
+        return lambda e: ramp(e) if e < w else max(
+            0.0, 0.5 * (1.0 + math.cos(math.pi * 0.5 * 2.0 * (float(e - w) / float(max(1, n - w))))))
+    if name == "cosine_with_restarts":
+        def f(e):
+            if e < w:
+                return ramp(e)
+            progress = float(e - w) / float(max(1, n - w))
+            return 0.0 if progress >= 1.0 else max(0.0, 0.5 * (1.0 + math.cos(math.pi * ((1.0 * progress) % 1.0))))
+        return f
+    lr_end, power = 1e-7, 1.0  # "polynomial"
+
+    def poly(e):
+        if e < w:
+            return ramp(e)
+        if e > n:
+            return lr_end / lr_init
+        remaining = 1 - (e - w) / (n - w)
+        return ((lr_init - lr_end) * remaining ** power + lr_end) / lr_init
+    return poly
+
+
 def lora_layers(model: nn.Module) -> List[LoraInjectedLinear]:
     """All LoraInjectedLinear modules in `model.modules()` order — for an injected model this is the
     enumeration order of lora.py:78-114, because every target is visited under its first matching ancestor."""
@@ -330,8 +375,9 @@ class FusedClipAdamW:
         self.norm = torch.zeros(4, dtype=torch.float32, device=slab.params.device)
         self.step_count = 0
 
-    def step(self, grad_mul: float = 1.0):
-        """One optimizer step on the current gradient slab; `grad_mul` = 1/(world_size·loss_scale).  `step_count` counts
+    def step(self, grad_mul: float = 1.0, lr_mul: float = 1.0):
+        """One optimizer step on the current gradient slab; `grad_mul` = 1/(world_size·loss_scale); `lr_mul` = the learning-rate
+        schedule's factor for this step (torch LambdaLR: every group's lr = its base lr · λ, a host scalar per launch).  `step_count` counts
         calls (it keys the on-device noise draw, which the reference also advances every iteration); the bias
         corrections use the number of APPLIED steps, kept on the device (`norm[2]`): an overflowed step is skipped and
         does not count, like torch.cuda.amp.GradScaler never calls optimizer.step() for it."""
@@ -347,11 +393,11 @@ class FusedClipAdamW:
             if g.get("rows") is not None:  # a table of which few rows ever get a gradient (TokenTable): same result, less traffic
                 V, D, active = g["rows"]
                 nat.lora_adamw_rows(s.params[a:b].view(V, D), s.grads[a:b].view(V, D), self.exp_avg[a:b].view(V, D),
-                                    self.exp_avg_sq[a:b].view(V, D), active, self.norm, grad_mul, self.max_grad_norm, g["lr"],
+                                    self.exp_avg_sq[a:b].view(V, D), active, self.norm, grad_mul, self.max_grad_norm, g["lr"] * lr_mul,
                                     self.betas[0], self.betas[1], self.eps, g.get("weight_decay", 1e-2), 0)
                 continue
             nat.lora_adamw_step(s.params[a:b], s.grads[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], self.norm,
-                                grad_mul, self.max_grad_norm, g["lr"], self.betas[0], self.betas[1], self.eps,
+                                grad_mul, self.max_grad_norm, g["lr"] * lr_mul, self.betas[0], self.betas[1], self.eps,
                                 g.get("weight_decay", 1e-2), 0)
 
     def grad_norm(self) -> float:
@@ -509,7 +555,17 @@ class TokenTable:
         self._pending = []
         self.module.forward = functools.partial(self._forward, self.module)  # (instance attribute: the class is untouched)
 
+    def check_ids(self, input_ids):
+        """torch.nn.Embedding raises on an id outside the table; the HIP gather cannot (it poisons the row with NaN, so the
+        step is skipped as an overflow).  Raise like torch wherever the check is free or cheap: ids still on the host, or a
+        host-launched pass (one small sync); never inside a stream capture."""
+        if input_ids.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            return
+        if input_ids.numel() and (int(input_ids.min()) < 0 or int(input_ids.max()) >= self.V):
+            raise IndexError(f"token id out of range for the {self.V}-row embedding table")
+
     def _forward(self, module, input_ids):
+        self.check_ids(input_ids)
         dt = torch.get_autocast_dtype("cuda") if (torch.is_autocast_enabled("cuda") and self.out_dtype != torch.float32) \
             else self.out_dtype
         if not module.weight.requires_grad or not torch.is_grad_enabled():
@@ -538,7 +594,9 @@ class LoraTrainer:
     def __init__(self, unet: nn.Module, text_encoder: Optional[nn.Module] = None, lr=1e-4, lr_text=5e-6,
                  weight_decay=1e-2, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0, loss_scale: Optional[float] = None,
                  v_prediction=False, process_group=None, always_reduce=False, capture_graph=False,
-                 group_projections=True, lr_embed: float = 5e-4, weight_decay_embed: Optional[float] = None):
+                 group_projections=True, lr_embed: float = 5e-4, weight_decay_embed: Optional[float] = None,
+                 lr_scheduler: str = "constant", lr_warmup_steps: int = 0, max_train_steps: Optional[int] = None,
+                 scheduler_steps_first: bool = False):
         """capture_graph: record add_noise → [text encoder] → UNet forward → loss → backward → factor gradients of a step
         once into a hipGraph and replay it on later steps with the same shapes (inputs are copied into static buffers).
         The gradient exchange and the optimizer stay outside the graph, so no collective is ever captured.  A step with a
@@ -549,8 +607,19 @@ class LoraTrainer:
         `set_use_memory_efficient_attention_xformers`).
         Token embeddings: when `text_encoder.get_input_embeddings().weight.requires_grad` is set — what the PTI tuning phase
         does under continue_inversion (cli_lora_pti.py:706-722) — the table trains too, with `lr_embed` (continue_inversion_lr /
-        learning_rate_ti, :713-715) and `weight_decay_embed` (default: `weight_decay`, one AdamW for all groups, :738)."""
+        learning_rate_ti, :713-715) and `weight_decay_embed` (default: `weight_decay`, one AdamW for all groups, :738).
+        Learning-rate schedule: `lr_scheduler` / `lr_warmup_steps` / `max_train_steps` are the trainers' arguments of the same
+        names (train_lora_dreambooth.py:298,345-358,737-743; cli_lora_pti.py: `lr_scheduler_lora`, `lr_warmup_steps_lora`,
+        `max_train_steps_tuning`, :534-535,746-751) and give λ (`lr_lambda`) on every group's lr.  `scheduler_steps_first`:
+        the dreambooth loop steps the scheduler AFTER the optimizer (:885-886: step k runs at λ(k), k = 0, 1, …), the PTI
+        tuning loop BEFORE it (cli_lora_pti.py:434: step k runs at λ(k + 1) — with the default linear schedule the first step
+        is already at lr·(1 − 1/N) and the last at 0).  The factor is a host scalar of the AdamW launch, which is outside a
+        recorded step anyway.  The schedule counts step() calls; under accelerate a GradScaler-skipped step holds the scheduler
+        back (AcceleratedScheduler), which matters for none of the reference's fp16 defaults ("constant"; PTI has no scaler)."""
         self.unet, self.text_encoder = unet, text_encoder
+        self.lr_lambda = lr_lambda(lr_scheduler, lr_warmup_steps, max_train_steps, lr_init=lr)
+        self.scheduler_steps_first = bool(scheduler_steps_first)
+        self.scheduler_epoch = 0  # calls of lr_scheduler.step() so far (LambdaLR.last_epoch)
         self.capture_graph = bool(capture_graph)
         self._graph = None
         models = [unet] + ([text_encoder] if text_encoder is not None and lora_layers(text_encoder) else [])
@@ -680,6 +749,19 @@ class LoraTrainer:
         return (self.loss_scale, self.v_prediction, tuple(float(l.scale) for l in layers),
                 tuple((l.linear.weight.data_ptr(), l.linear.weight._version) for l in layers), ff2)
 
+    def _scheduled_lr_factor(self) -> float:
+        """λ for the optimizer launch of this step, and the scheduler's own step() before or after it."""
+        if self.scheduler_steps_first:
+            self.scheduler_epoch += 1
+            return float(self.lr_lambda(self.scheduler_epoch))
+        self.scheduler_epoch += 1
+        return float(self.lr_lambda(self.scheduler_epoch - 1))
+
+    def get_last_lr(self) -> List[float]:
+        """`lr_scheduler.get_last_lr()` (what the trainers log, train_lora_dreambooth.py:959): one value per param group."""
+        lam = float(self.lr_lambda(self.scheduler_epoch))
+        return [g["lr"] * lam for g in self.opt.groups]
+
     # -- one step ---------------------------------------------------------------------------------
     def step(self, latents, noise, timesteps, encoder_hidden_states=None, *, with_prior_preservation=False,
              prior_loss_weight=1.0, mask=None, seed: Optional[int] = None, input_ids=None, t_multiplier: float = 1.0):
@@ -695,6 +777,8 @@ class LoraTrainer:
             raise ValueError("pass exactly one of encoder_hidden_states and input_ids")
         if input_ids is not None and self.text_encoder is None:
             raise ValueError("input_ids given but the trainer has no text encoder")
+        if self.token_table is not None and input_ids is not None and input_ids.device.type == "cpu":
+            self.token_table.check_ids(input_ids)  # (free on the host; a replayed step cannot check device-resident ids)
         self._poll_overflow()
         recordable = not self.trains_text_encoder or input_ids is not None
         if self.capture_graph and recordable:
@@ -754,7 +838,7 @@ class LoraTrainer:
         self.exchange.finish()
         if self.token_table is not None:
             self.token_table.collect(self.pg, self.world if self.exchange.active else 1)
-        self.opt.step(grad_mul=1.0 / (self.world * self.loss_scale))
+        self.opt.step(grad_mul=1.0 / (self.world * self.loss_scale), lr_mul=self._scheduled_lr_factor())
         self._watch_overflow()
         self.slab.repack()  # forwards outside step() (sampling, evaluation, saving merged weights) see the new factors
         return loss
@@ -829,6 +913,9 @@ class LoraTrainer:
                 with torch.cuda.graph(g, capture_error_mode=mode):
                     self._graph_body(st)
                 st["graph"] = g
+                # the (ids, gradient rows) buffers the RECORDING writes on every replay belong to the recording, not to the
+                # table: an eager step in between resets the table's list (begin_pass), a replay cannot refill it
+                st["token_pending"] = list(self.token_table._pending) if self.token_table is not None else None
             except Exception as exc:  # keep training: this trainer falls back to host-launched steps for good
                 import warnings
 
@@ -849,8 +936,9 @@ class LoraTrainer:
             tail[-1][0].record()
         self.exchange.finish()
         if self.token_table is not None:
+            self.token_table._pending = list(st["token_pending"])
             self.token_table.collect(self.pg, self.world if self.exchange.active else 1)
-        self.opt.step(grad_mul=1.0 / (self.world * self.loss_scale))
+        self.opt.step(grad_mul=1.0 / (self.world * self.loss_scale), lr_mul=self._scheduled_lr_factor())
         self._watch_overflow()
         self.slab.repack()
         if tail is not None:

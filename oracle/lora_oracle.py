@@ -214,6 +214,16 @@ def adamw_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_de
     p.addcdiv_(m, denom, value=-(lr / bc1))
 
 
+def linear_schedule_factor(epoch: int, num_warmup_steps: int, num_training_steps: int) -> float:
+    """λ(epoch) of get_scheduler("linear", …) — cli_lora_pti.py:746-751 (default `lr_scheduler_lora="linear"`, 0 warm-up
+    steps, :534-535), train_lora_dreambooth.py:737-743 with --lr_scheduler linear.  diffusers' function (third party, not in
+    the reference tree): a torch LambdaLR with a linear ramp over the warm-up steps and a linear decay to 0 at
+    num_training_steps — restated from its published definition, parity unpinned for the formula itself."""
+    if epoch < num_warmup_steps:
+        return float(epoch) / float(max(1, num_warmup_steps))
+    return max(0.0, float(num_training_steps - epoch) / float(max(1, num_training_steps - num_warmup_steps)))
+
+
 # ------------------------------------------------------------------------------------------------
 # row H: the step harness (train_lora_dreambooth.py:811-888), synthetic latents instead of VAE/CLIP
 # ------------------------------------------------------------------------------------------------
@@ -233,12 +243,14 @@ def synthetic_batch(step: int, batch: int, latent_hw: int, ctx_len: int, ctx_dim
 def train_steps(unet, params: List[torch.Tensor], steps: int, batch: int, latent_hw: int, ctx_len: int,
                 ctx_dim: int, lr=1e-4, weight_decay=1e-2, max_grad_norm=1.0, with_prior=False,
                 prior_loss_weight=1.0, v_prediction=False, world: int = 1, first_step: int = 0,
-                state: Optional[dict] = None):
+                state: Optional[dict] = None, lr_schedule=None):
     """`steps` optimizer steps of the reference loop on CPU.  `world` > 1 emulates synchronous data
     parallelism: each virtual rank takes its own slice of a `world*batch` batch and the gradients are
     averaged (DDP mean all-reduce, train_lora_dreambooth.py:744-757,877).  Returns the loss history.
     `state`: a dict that carries the optimizer state (Adam moments, step count) from one call to the next, so that a
-    trajectory can be produced in pieces (a test that looks at the gradients of the first step, then continues)."""
+    trajectory can be produced in pieces (a test that looks at the gradients of the first step, then continues).
+    `lr_schedule`: λ(epoch) on the learning rate; this loop calls lr_scheduler.step() AFTER optimizer.step()
+    (train_lora_dreambooth.py:885-886), so optimizer step k (from 0) runs at lr·λ(k)."""
     acp = ddpm_alphas_cumprod()
     if state is not None and "m" in state:
         m, v, done = state["m"], state["v"], state["t"]
@@ -264,7 +276,9 @@ def train_steps(unet, params: List[torch.Tensor], steps: int, batch: int, latent
         clip_grad_norm(grads, max_grad_norm)
         for p, g, mm, vv in zip(params, grads, m, v):
             with torch.no_grad():
-                adamw_step(p, g, mm, vv, done + s - first_step + 1, lr, weight_decay=weight_decay)
+                adamw_step(p, g, mm, vv, done + s - first_step + 1,
+                           lr * (lr_schedule(done + s - first_step) if lr_schedule is not None else 1.0),
+                           weight_decay=weight_decay)
         losses.append(sum(step_losses) / world)
     if state is not None:
         state.update(m=m, v=v, t=done + steps)
@@ -299,13 +313,15 @@ def synthetic_token_ids(step: int, batch: int, ctx_len: int, vocab: int, seed_ba
 def pti_tuning_steps(unet, text_encoder, lora_params: List[torch.Tensor], steps: int, batch: int, latent_hw: int,
                      ctx_len: int, vocab: int, lr_unet=1e-4, lr_embed=5e-4, weight_decay=1e-3, max_grad_norm=1.0,
                      v_prediction=True, t_multiplier=0.8, masks: Optional[Sequence[torch.Tensor]] = None, first_step: int = 0,
-                     bos: int = 1, eos: int = 2):
+                     bos: int = 1, eos: int = 2, lr_schedule=None):
     """`steps` iterations of perform_tuning (cli_lora_pti.py:424-451) with the optimizer of :738 —
     AdamW([{unet LoRA, lr_unet}, {token table, continue_inversion_lr | ti_lr}], weight_decay=weight_decay_lora) — on synthetic
     latents: loss_step's draw `randint(0, int(1000·t_mutliplier))` (:190-195, 0.8 at :444), add_noise, the text encoder INSIDE
     the step (:199-206), ε- or v-target (:215-220), optional mask (:222-245), mse (:247); backward; clip_grad_norm_ over
     chain(unet.parameters(), text_encoder.parameters()) (:448-450); step.  fp32 (the reference autocasts; the parity target
-    is the fp32 arithmetic).  Returns the loss history; `lora_params` and the token table are updated in place."""
+    is the fp32 arithmetic).  Returns the loss history; `lora_params` and the token table are updated in place.
+    `lr_schedule`: λ(epoch); perform_tuning calls `lr_scheduler_lora.step()` BEFORE every batch (:434), so iteration k (from 0)
+    runs at lr·λ(k + 1) — with the default linear schedule (:534-535,746-751) the first step is already at lr·(1 − 1/N)."""
     acp = ddpm_alphas_cumprod()
     table = text_encoder.get_input_embeddings().weight
     params = list(lora_params) + [table]
@@ -329,7 +345,8 @@ def pti_tuning_steps(unet, text_encoder, lora_params: List[torch.Tensor], steps:
         clip_grad_norm(grads, max_grad_norm)
         for p, g, mm, vv, lr in zip(params, grads, m, v, lrs):
             with torch.no_grad():
-                adamw_step(p, g, mm, vv, s - first_step + 1, lr, weight_decay=weight_decay)
+                adamw_step(p, g, mm, vv, s - first_step + 1,
+                           lr * (lr_schedule(s - first_step + 1) if lr_schedule is not None else 1.0), weight_decay=weight_decay)
         losses.append(loss.item())
     return losses
 

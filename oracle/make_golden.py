@@ -95,6 +95,44 @@ def gen_operator(ref):
     save_file({k: v.contiguous() for k, v in tensors.items()}, os.path.join(OUT, "operator.safetensors"), meta)
 
 
+def matrix_digest(y, dx, g_down, g_up, K, N, seed):
+    """What operator_matrix.safetensors keeps of one case's outputs (float64 in, small tensors out): the first and last
+    rows of Y and dX in full, and the projections of all four outputs onto seeded probe matrices (oracle/synthetic.probes) —
+    the wide outputs themselves would be 24 MB over the 96 cases."""
+    from oracle import synthetic as syn
+
+    pn, pk = syn.probes(N, seed), syn.probes(K, seed + 1)
+    return {"y.rows": y[[0, -1]].float(), "dx.rows": dx[[0, -1]].float(), "y.proj": y.double() @ pn, "dx.proj": dx.double() @ pk,
+            "g_down.proj": g_down.double() @ pk, "g_up.proj": pn.t() @ g_up.double()}
+
+
+def gen_operator_matrix(ref):
+    """SURVEY §8(c)'s operator matrix: the REFERENCE's LoraInjectedLinear (lora.py:32-50, run in float64) and autograd on every
+    SD1.5 LoRA layer kind — the 9 (K, N) pairs, square ones with and without bias as diffusers has them — × r ∈ {1, 4, 8, 16}
+    × scale ∈ {1, 0.7}; inputs are oracle/synthetic.py's integer-hash operands (fp16-exact, not stored)."""
+    from oracle import synthetic as syn
+
+    tensors, meta = {}, {}
+    for tag, K, N, bias, M, r, scale, seed in syn.matrix_cases():
+        x, w, b, dy, down, up = syn.matrix_inputs(K, N, bias, M, r, seed)
+        layer = ref.LoraInjectedLinear(K, N, bias, r).double()
+        with torch.no_grad():
+            layer.linear.weight.copy_(w)
+            if bias:
+                layer.linear.bias.copy_(b)
+            layer.lora_down.weight.copy_(down)
+            layer.lora_up.weight.copy_(up)
+        layer.scale = scale
+        layer.linear.requires_grad_(False)
+        xin = x.double().requires_grad_(True)
+        y = layer(xin)
+        y.backward(dy.double())
+        d = matrix_digest(y.detach(), xin.grad, layer.lora_down.weight.grad, layer.lora_up.weight.grad, K, N, seed)
+        tensors.update({f"{tag}.{k}": v for k, v in d.items()})
+        meta[tag] = json.dumps({"M": M, "K": K, "N": N, "r": r, "bias": bias, "scale": scale, "seed": seed})
+    save_file({k: v.contiguous() for k, v in tensors.items()}, os.path.join(OUT, "operator_matrix.safetensors"), meta)
+
+
 def gen_losses():
     g = torch.Generator().manual_seed(99)
     tensors = {}
@@ -275,8 +313,13 @@ def gen_trajectory(ref):
     save_file(tensors, os.path.join(OUT, "trajectory.safetensors"), meta)
 
 
-def gen_pti_trajectory(ref):
-    """BASELINE config 5's second half — the PTI tuning phase with continue_inversion (cli_lora_pti.py:693-753): the REFERENCE's
+def gen_pti_trajectory(ref, linear_schedule=False):
+    """(linear_schedule: the run as perform_tuning really schedules it by default — `get_scheduler("linear", optimizer,
+    num_warmup_steps=0, num_training_steps=max_train_steps_tuning)`, cli_lora_pti.py:534-535,746-751, stepped BEFORE every
+    batch, :434.  diffusers is absent here; its "linear" is a torch LambdaLR whose λ is restated below from the published
+    definition (parity unpinned for that formula) — torch's LambdaLR, AdamW and the reference's LoRA modules do the rest.
+    Written to pti_trajectory_linear.safetensors: results only, the inputs are pti_trajectory.safetensors'.)
+    BASELINE config 5's second half — the PTI tuning phase with continue_inversion (cli_lora_pti.py:693-753): the REFERENCE's
     inject_trainable_lora on the tiny UNet, the token table of a tiny transformers CLIPTextModel as the second AdamW group
     (:706-722,738), loss_step's arithmetic (:170-248: draw below int(1000·0.8), text encoder inside the step, v-prediction
     target, mse), clip_grad_norm_ over chain(unet.parameters(), text_encoder.parameters()) (:448-450).  cli_lora_pti.py itself
@@ -309,9 +352,17 @@ def gen_pti_trajectory(ref):
     tensors.update({f"te.{n}": p.detach().clone() for n, p in te.named_parameters() if p is not table})
     opt = torch.optim.AdamW([{"params": plist, "lr": 1e-3}, {"params": te.get_input_embeddings().parameters(), "lr": 5e-3}],
                             weight_decay=1e-3)                           # :726-738 (weight_decay_lora)
+    sched = None
+    if linear_schedule:                                                  # :746-751
+        warm, total = 0, steps
+        sched = torch.optim.lr_scheduler.LambdaLR(
+            opt, lambda e: float(e) / float(max(1, warm)) if e < warm else max(0.0, float(total - e) / float(max(1, total - warm))))
     acp = orc.ddpm_alphas_cumprod()
-    losses, all_ids = [], []
+    losses, all_ids, lrs = [], [], []
     for step in range(steps):
+        if sched is not None:
+            sched.step()                                                 # :434
+            lrs.append(sched.get_last_lr())
         latents, noise, t, _ = orc.synthetic_batch(step, batch, 8, ctx_len, 32, t_max=int(1000 * 0.8))   # :190-195, :444
         ids = orc.synthetic_token_ids(step, batch, ctx_len, vocab)
         all_ids.append(ids)
@@ -328,6 +379,13 @@ def gen_pti_trajectory(ref):
     tensors["lora.final"] = orc.flat_params(plist).clone()
     tensors["table.final"] = table.detach().clone()
     tensors["losses"] = torch.tensor(losses)
+    if linear_schedule:
+        out = {"lora.final": tensors["lora.final"], "table.final": tensors["table.final"], "losses": tensors["losses"],
+               "lrs": torch.tensor(lrs, dtype=torch.float64)}
+        save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(OUT, "pti_trajectory_linear.safetensors"),
+                  {"schedule": json.dumps({"name": "linear", "num_warmup_steps": 0, "num_training_steps": steps,
+                                           "stepped": "before the optimizer (cli_lora_pti.py:434)"})})
+        return
     tensors["ids"] = torch.stack(all_ids)
     meta = {"cfg": json.dumps({"vocab": vocab, "ctx_len": ctx_len, "steps": steps, "batch": batch, "latent_hw": 8,
                                "hidden": 32, "intermediate": 64, "layers": 2, "heads": 2, "lr_unet": 1e-3, "lr_embed": 5e-3,
@@ -343,12 +401,14 @@ def main():
     torch.set_num_threads(8)
     ref = import_reference_lora()
     gen_operator(ref)
+    gen_operator_matrix(ref)
     gen_losses()
     gen_merge(ref)
     with tempfile.TemporaryDirectory() as d:
         gen_finder_and_formats(ref, d)
     gen_trajectory(ref)
     gen_pti_trajectory(ref)
+    gen_pti_trajectory(ref, linear_schedule=True)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -48,6 +48,16 @@ def golden_pti():
 
 
 @pytest.fixture(scope="session")
+def golden_pti_linear():
+    return _load("pti_trajectory_linear.safetensors")
+
+
+@pytest.fixture(scope="session")
+def golden_operator_matrix():
+    return _load("operator_matrix.safetensors")
+
+
+@pytest.fixture(scope="session")
 def golden_structure():
     with open(os.path.join(GOLDEN, "structure.json")) as f:
         return json.load(f)

@@ -34,6 +34,44 @@ def test_failing_rank_gives_nonzero_exit_code():
     assert not _json_lines(res.stdout)
 
 
+def test_world_8_rehearsal_at_the_drivers_shape():
+    """What an 8-GPU node meets first, on gloo/CPU: `bench.py --gpus 8` under its own launcher — eight ranks, the real
+    SlabExchange (one whole-slab all-reduce per step), the replica-signature check, ONE JSON line whose `config` reports the
+    process group's own world size and backend."""
+    res = _run("--gpus", "8", "--steps", "3", "--warmup", "1", "--stub-body", "ok")
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = _json_lines(res.stdout)
+    assert len(lines) == 1, res.stdout
+    line = lines[0]
+    assert line["n_gpus"] == 8 and line["value"] == 36.0 and line["scaling"] == "weak"  # 1 + … + 8: all ranks in the all-reduce
+    assert line["config"] == {"parallelism": "dp8", "rccl_ranks": 8, "backend": "gloo"}
+
+
+def test_world_8_diverged_replica_ends_the_run_with_exit_code_4():
+    """A replica that trained on something else (here: the last rank's step 1 never went through the exchange) must end the
+    run with the divergence code instead of a number."""
+    res = _run("--gpus", "8", "--steps", "3", "--warmup", "1", "--stub-body", "diverge")
+    assert res.returncode != 0
+    assert not _json_lines(res.stdout)
+    assert "LoRA slab differs across ranks" in res.stderr and "exitcode  : 4" in res.stderr  # (torchrun's failure report)
+
+
+def test_eight_ranks_refuse_to_share_the_visible_devices():
+    """One process per GPU: on a node that shows fewer devices than local ranks (this container shows none) every rank of the
+    REAL body exits with code 5 before anything touches a device — two ranks time-slicing one GPU must never be reported as
+    N GPUs; `--shared-gpu` is the explicit rehearsal switch."""
+    import torch
+
+    if torch.cuda.device_count() >= 8:
+        import pytest
+
+        pytest.skip("a full node: nothing to refuse")
+    res = _run("--gpus", "8", "--steps", "1", "--warmup", "0", "--no-extra", "--no-cpu-baseline")
+    assert res.returncode != 0
+    assert not _json_lines(res.stdout)
+    assert "visible GPU(s) for 8 ranks" in res.stderr and "--shared-gpu" in res.stderr
+
+
 def test_single_rank_runs_in_process():
     res = _run("--gpus", "1", "--stub-body", "ok")
     assert res.returncode == 0, res.stderr[-2000:]

@@ -123,6 +123,47 @@ def test_factor_gradients_matrix_core_edges(close, dtype):
         close(got, ref, tol, (M, C, r, kn, st))
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_factor_gradients_keep_their_precision_at_any_magnitude_of_p(close, dtype):
+    """P = T = X·Aᵀ is not scaled by anything and P = U = dY·B shrinks with the loss scale: the matrix-core kernel's fp16
+    hi + lo split of P is exact only between 2^-3 and 65504 unless P is re-centred — it is, per rank column and row block,
+    by a power of two (lora_grad.hip).  Columns of very different magnitudes in ONE problem — 1e-6 (lo AND hi would be fp16
+    subnormals), 1e5 (beyond fp16's largest finite value: inf → NaN gradients without the scaling), 1 — rows whose
+    magnitudes differ by 2^10 inside a block, row blocks of different magnitudes: same tolerance as at magnitude 1."""
+    g = torch.Generator().manual_seed(5)
+    specs = [(1500, 328, 16, True), (700, 264, 4, False), (513, 72, 8, True), (40, 1288, 3, False)]
+    col_mag = torch.tensor([1e-6, 1e5, 1.0, 3e-4, 2e4, 1e-5, 1e2, 1e-2] * 2)
+    off, offs = 0, []
+    for (M, C, r, kn) in specs:
+        offs.append(off)
+        off += r * C
+    stride = (off + 3) // 4 * 4
+    partials = torch.full((nat.GRAD_MAX_BLOCKS, stride), float("nan"), device=DEV)
+    problems, refs, keep, ranges = [], [], [], []
+    for (M, C, r, kn), o in zip(specs, offs):
+        S = torch.randn(M, C, generator=g).to(dtype).to(DEV)
+        P = torch.randn(M, r, generator=g) * col_mag[:r]
+        P[::7] *= 2.0 ** -10          # a spread inside every row block
+        P[512:1024] *= 2.0 ** 6       # the second row block lives elsewhere
+        P = P.to(DEV)
+        problems.append(nat.grad_problem(S, 0, C, C, P, 0, r, r, [partials.data_ptr() + 4 * o], r, kn, stride, M, 0.7))
+        keep.append((S, P))
+        refs.append(_ref_grad(S, P, 0.7))
+        ranges.append([o, r * C, nat.grad_row_blocks(M), 0])
+    nat.lora_grad_batched(problems, dtype, torch.device(DEV, 0))
+    grads = torch.zeros(stride, device=DEV)
+    table = torch.tensor(ranges, dtype=torch.int64).to(DEV)
+    nat.lora_fold_partials(table, len(ranges), max(r_[1] for r_ in ranges), partials, stride, grads, False)
+    torch.cuda.synchronize()
+    assert torch.isfinite(grads).all()
+    tol = 2e-5 if dtype == torch.float16 else 6e-5
+    for (M, C, r, kn), o, ref in zip(specs, offs, refs):
+        got = grads[o:o + r * C]
+        got = got.view(r, C).t() if kn else got.view(C, r)
+        for j in range(r):  # every rank column on its own scale: the big ones must not hide the small ones
+            close(got[:, j:j + 1].reshape(1, -1), ref[:, j:j + 1].reshape(1, -1), tol, (M, C, r, kn, j))
+
+
 def test_pack_items_layouts():
     """lora_pack_items: per-layer [A16|At16], [Bt16|B16] and the block-diagonal q/k/v layout (rows = r, destinations
     offset, buffer zeroed once)."""
@@ -580,11 +621,13 @@ def test_full_size_fp16_trajectory_vs_fp32_cpu_oracle(relerr, prior, steps):
     print(f"cfg-{4 if prior else 2} f16, {steps} steps vs fp32 oracle: max loss err {lerr:.2e}; step-1 gradient direction err "
           f"{relerr(gn, rn):.2e} (worst layer {worst:.2e}), |g|-weighted update-sign agreement {wsign:.4f}; update err after "
           f"{steps} steps {uerr:.3e}; state err {relerr(got, want):.2e}")
-    assert lerr < 2e-3, lerr
-    assert relerr(gn, rn) < 1e-2 and worst < 5e-2, (relerr(gn, rn), worst)
-    assert wsign > 0.995, wsign
+    # bounds = at most 2× what the committed kernels measure (round 4: loss 5.8e-5 / 9.3e-5, direction 1.3e-3, worst layer
+    # 2.2e-2 / 1.8e-2, sign agreement 0.9985, update 6.2e-2 / 7.4e-2): a single layer computed wrongly moves `worst` to O(1)
+    assert lerr < 2e-4, lerr
+    assert relerr(gn, rn) < 2.6e-3 and worst < 4.4e-2, (relerr(gn, rn), worst)
+    assert wsign > 0.997, wsign
     assert uerr < 0.1, uerr
-    assert relerr(got, want) < 1e-3
+    assert relerr(got, want) < 1e-3  # (north_star's bound on the state; vacuous on its own after a few steps of lr 1e-4)
 
 
 def _copy_frozen(ref_state, model):
@@ -594,17 +637,19 @@ def _copy_frozen(ref_state, model):
 def _check_update(got, want, init, grad, ref_grad, offsets, relerr, loss, ref_loss):
     """Single-step configs: loss, direction of the gradient slab, and the UPDATE — Adam's first step is ≈ lr·sign(g), so the
     update is judged by its signs, weighted by |g| (the state itself would pass un-updated: lr 1e-4 on factors of 0.01–0.25)."""
-    assert abs(loss - ref_loss) / abs(ref_loss) < 3e-3, (loss, ref_loss)
+    # (bounds ≤ 2× the measured values of the committed kernels: loss 4.5e-5, direction 1.3e-3, worst layer 4.7e-2 — the
+    #  rank-8 CLIP layers of config 3 — element signs 0.990, gradient-mass signs 0.998)
+    assert abs(loss - ref_loss) / abs(ref_loss) < 1e-4, (loss, ref_loss)
     gn, rn = grad / grad.norm(), ref_grad / ref_grad.norm()
-    assert relerr(gn, rn) < 1.5e-2, relerr(gn, rn)
+    assert relerr(gn, rn) < 2.7e-3, relerr(gn, rn)
     worst = max(relerr(gn[o:o + n], rn[o:o + n]) for o, n in offsets)
     assert worst < 8e-2, worst
     agree = (((got - init) * (want - init)) > 0).float().mean().item()
     wsign = weighted_sign_agreement(got - init, want - init, ref_grad)
     print(f"single step: loss err {abs(loss - ref_loss) / abs(ref_loss):.2e}, gradient direction err {relerr(gn, rn):.2e} "
           f"(worst layer {worst:.2e}), update signs agree on {agree:.4f} of the elements / {wsign:.4f} of the gradient mass")
-    assert agree > 0.96, agree
-    assert wsign > 0.99, wsign
+    assert agree > 0.98, agree
+    assert wsign > 0.996, wsign
     assert float((got - init).abs().max()) > 0.5e-4  # the step was applied (|Δ| ≈ lr = 1e-4)
 
 

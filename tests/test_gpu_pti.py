@@ -97,6 +97,71 @@ def test_pti_tuning_trajectory_matches_the_reference_produced_one(golden_pti, re
     assert te.get_input_embeddings().weight.data_ptr() == trainer.slab.params[trainer.token_table.range[0]:].data_ptr()
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_pti_tuning_trajectory_under_the_default_linear_schedule(golden_pti, golden_pti_linear, relerr, graph):
+    """perform_tuning's default schedule — get_scheduler("linear", 0 warm-up steps, max_train_steps_tuning), stepped BEFORE
+    every batch (cli_lora_pti.py:434,534-535,746-751): the fused trainer's `lr_scheduler` / `max_train_steps` /
+    `scheduler_steps_first` against the trajectory torch's LambdaLR + AdamW produced around the reference's LoRA modules
+    (tests/golden/pti_trajectory_linear.safetensors), fp32: state within 1e-5, the accumulated update within 2e-2 (the
+    constant-rate test's bound), the logged learning rates equal to the fixture's."""
+    t, meta = golden_pti
+    lin, lmeta = golden_pti_linear
+    cfg, sch = json.loads(meta["cfg"]), json.loads(lmeta["schedule"])
+    unet, te = build_pti_models(t, cfg, DEV, torch.float32)
+    params, _ = dfa.inject_trainable_lora(unet, r=4)
+    plist = list(itertools.chain(*params))
+    with torch.no_grad():
+        for p, v in zip(plist, torch.split(t["lora.init"], [q.numel() for q in plist])):
+            p.copy_(v.view(p.shape).to(DEV))
+    set_use_memory_efficient_attention_xformers(unet, True)
+    orc.freeze_all_but_token_embeddings(te)
+    trainer = tr.LoraTrainer(unet, te, lr=cfg["lr_unet"], lr_embed=cfg["lr_embed"], weight_decay=cfg["weight_decay"],
+                             v_prediction=cfg["v_prediction"], capture_graph=graph, lr_scheduler=sch["name"],
+                             lr_warmup_steps=sch["num_warmup_steps"], max_train_steps=sch["num_training_steps"],
+                             scheduler_steps_first=True)
+    losses = []
+    for s in range(cfg["steps"]):
+        lat, noise, ts, _ = orc.synthetic_batch(s, cfg["batch"], cfg["latent_hw"], cfg["ctx_len"], cfg["hidden"],
+                                                t_max=int(1000 * cfg["t_multiplier"]))
+        losses.append(trainer.step(lat.to(DEV), noise.to(DEV), ts.to(DEV), input_ids=t["ids"][s].to(DEV)))
+        assert max(abs(a - b) for a, b in zip(trainer.get_last_lr(), lin["lrs"][s].tolist())) < 1e-12
+    losses = torch.stack(losses).reshape(-1).cpu()
+    table = te.get_input_embeddings().weight.detach().cpu()
+    assert relerr(losses, lin["losses"]) < 1e-4, relerr(losses, lin["losses"])
+    assert relerr(tr.flat_lora_state(unet).cpu(), lin["lora.final"]) < 1e-5, relerr(tr.flat_lora_state(unet).cpu(), lin["lora.final"])
+    assert relerr(table, lin["table.final"]) < 1e-5, relerr(table, lin["table.final"])
+    assert relerr(tr.flat_lora_state(unet).cpu() - t["lora.init"], lin["lora.final"] - t["lora.init"]) < 2e-2
+    assert relerr(table - t["table.init"], lin["table.final"] - t["table.init"]) < 2e-2
+    # the constant-rate trajectory is somewhere else entirely
+    assert relerr(tr.flat_lora_state(unet).cpu() - t["lora.init"], t["lora.final"] - t["lora.init"]) > 0.2
+
+
+def test_replay_after_a_host_launched_step_still_sums_the_recordings_gradient_rows(golden_pti, relerr):
+    """A recorded step's (ids, gradient rows) buffers belong to the RECORDING: a host-launched step in between (the caller
+    toggles `capture_graph`, or hands over a step that is not recordable) resets the table's own list, and the next replay
+    must still sum the rows its kernels just wrote — graph, eager, graph, graph … equals the all-eager trajectory."""
+    t, meta = golden_pti
+    cfg = json.loads(meta["cfg"])
+    want_tr, want_unet, want_te = _tiny_trainer(t, cfg, torch.float32, graph=False)
+    want_losses = _run_tiny(t, cfg, want_tr, steps=6)
+    trainer, unet, te = _tiny_trainer(t, cfg, torch.float32, graph=True)
+    losses = []
+    for s in range(6):
+        trainer.capture_graph = s != 2  # steps 0, 1 replayed; 2 host-launched; 3.. replayed from the SAME recording
+        lat, noise, ts, _ = orc.synthetic_batch(s, cfg["batch"], cfg["latent_hw"], cfg["ctx_len"], cfg["hidden"],
+                                                t_max=int(1000 * cfg["t_multiplier"]))
+        losses.append(trainer.step(lat.to(DEV), noise.to(DEV), ts.to(DEV), input_ids=t["ids"][s].to(DEV)))
+        if s == 1:
+            recording = trainer._graph["graph"]
+    assert trainer._graph["graph"] is recording  # not re-recorded: the replay after the eager step is the old recording
+    losses = torch.stack(losses).reshape(-1).cpu()
+    assert relerr(losses, want_losses) < 1e-5, relerr(losses, want_losses)
+    got, want = te.get_input_embeddings().weight.detach(), want_te.get_input_embeddings().weight.detach()
+    assert relerr(got - t["table.init"].to(DEV), want - t["table.init"].to(DEV)) < 1e-4, \
+        relerr(got - t["table.init"].to(DEV), want - t["table.init"].to(DEV))
+    assert relerr(tr.flat_lora_state(unet), tr.flat_lora_state(want_unet)) < 1e-5
+
+
 def test_grouped_context_projection_produces_the_context_gradient(relerr):
     """With a context that carries a gradient the attn2 to_k/to_v of all blocks still run as ONE forward launch, and their dX
     comes from one launch over the concatenated contraction (groups._CtxProjFn.backward) — the f16 trajectory, token table
@@ -282,10 +347,22 @@ def test_new_entry_points_edge_cases():
     grad = torch.full((3, 4), 7.0, device=DEV)
     nat.embed_rows_bwd(torch.empty(0, 4, dtype=torch.float16, device=DEV), empty, grad)
     assert torch.equal(grad, torch.full_like(grad, 7.0))
-    ids = torch.tensor([5, -1, 1], device=DEV)                       # forward clamps, backward skips what is out of range
-    assert torch.equal(nat.embed_rows_fwd(table, ids, torch.float32), table[torch.tensor([2, 0, 1], device=DEV)])
+    # an id outside the table (torch.nn.Embedding raises): the C entry points treat it the SAME way in both directions — the
+    # forward row is poisoned with NaN (never another token's row), the backward drops the position — and the binding layer
+    # raises like torch wherever it can look at the ids (TokenTable.check_ids)
+    ids = torch.tensor([5, -1, 1], device=DEV)
+    for dt in (torch.float32, torch.float16, torch.bfloat16):
+        rows = nat.embed_rows_fwd(table, ids, dt)
+        assert torch.isnan(rows[:2]).all() and torch.equal(rows[2], table[1].to(dt))
     nat.embed_rows_bwd(torch.ones(3, 4, device=DEV), ids, grad)
     assert torch.equal(grad[1], torch.ones(4, device=DEV)) and torch.equal(grad[0], torch.full((4,), 7.0, device=DEV))
+    assert torch.equal(grad[2], torch.full((4,), 7.0, device=DEV))
+    tt = tr.TokenTable.__new__(tr.TokenTable)
+    tt.V = 3
+    tt.check_ids(torch.tensor([[0, 2]]))
+    for bad in (ids, ids.cpu(), torch.tensor([3])):
+        with pytest.raises(IndexError):
+            tt.check_ids(bad)
 
     K = N = 64
     x = torch.randn(16, K, device=DEV).half()

@@ -25,6 +25,38 @@ def test_operator_forward_backward(golden_operator, relerr):
         assert relerr(g_up, t[f"{c}.g_up"]) < TOL
 
 
+def matrix_digest(y, dx, g_down, g_up, K, N, seed):
+    """The digest oracle/make_golden.py::matrix_digest stores per case (same arithmetic, restated for the checker side)."""
+    from oracle import synthetic as syn
+
+    pn, pk = syn.probes(N, seed), syn.probes(K, seed + 1)
+    y, dx, g_down, g_up = (v.detach().double().cpu() for v in (y, dx, g_down, g_up))
+    return {"y.rows": y[[0, -1]], "dx.rows": dx[[0, -1]], "y.proj": y @ pn, "dx.proj": dx @ pk, "g_down.proj": g_down @ pk,
+            "g_up.proj": pn.t() @ g_up}
+
+
+def test_operator_matrix_of_every_sd_layer_kind(golden_operator_matrix, relerr):
+    """SURVEY §8(c)'s matrix — 12 layer kinds (the 9 SD1.5 (K, N) pairs, square ones with and without bias) × r ∈ {1,4,8,16} ×
+    scale ∈ {1, 0.7}, produced by the REFERENCE's module in float64 on integer-hash inputs: the oracle in float64 reproduces the
+    stored rows and projections to rounding (the rows are stored in fp32)."""
+    from oracle import synthetic as syn
+
+    t, meta = golden_operator_matrix
+    cases = syn.matrix_cases()
+    assert len(cases) == 96 and {c[0] for c in cases} == set(meta)
+    for tag, K, N, bias, M, r, scale, seed in cases:
+        cfg = json.loads(meta[tag])
+        assert (cfg["M"], cfg["K"], cfg["N"], cfg["r"], cfg["bias"], cfg["scale"], cfg["seed"]) == (M, K, N, r, bias, scale, seed)
+        x, w, b, dy, down, up = (None if v is None else v.double() for v in syn.matrix_inputs(K, N, bias, M, r, seed))
+        assert torch.equal(w.half().double(), w) and torch.equal(x.half().double(), x)  # fp16-exact operands
+        y = orc.lora_linear_forward(x, w, b, down, up, scale)
+        dx, g_down, g_up = orc.lora_linear_backward(x, w, down, up, scale, dy)
+        for k, v in matrix_digest(y, dx, g_down, g_up, K, N, seed).items():
+            want = t[f"{tag}.{k}"]
+            assert v.shape == want.shape
+            assert relerr(v, want) < (1e-7 if k.endswith("rows") else 1e-12), (tag, k, relerr(v, want))
+
+
 def test_operator_module_matches_reference_init_and_error(golden_operator):
     _, meta = golden_operator
     torch.manual_seed(7)
@@ -196,3 +228,36 @@ def test_pti_tuning_trajectory_with_trainable_token_embeddings(golden_pti, reler
     unused[t["ids"].reshape(-1)] = False
     decay = (1 - cfg["lr_embed"] * cfg["weight_decay"]) ** cfg["steps"]
     assert unused.any() and relerr(table.detach()[unused], t["table.init"][unused] * decay) < 1e-6
+
+
+def test_pti_tuning_trajectory_under_the_default_linear_schedule(golden_pti, golden_pti_linear, relerr):
+    """perform_tuning as it schedules by default: get_scheduler("linear", 0 warm-up steps, max_train_steps_tuning)
+    (cli_lora_pti.py:534-535,746-751) stepped BEFORE every batch (:434) — the fixture was produced with torch's LambdaLR around
+    the reference's LoRA modules; the oracle's λ (linear_schedule_factor) and its placement reproduce the learning rates and
+    the trajectory; the product's `lr_lambda` gives the same factors."""
+    from diffusion_finetuning_amd.trainer import lr_lambda
+
+    t, meta = golden_pti
+    lin, lmeta = golden_pti_linear
+    cfg, sch = json.loads(meta["cfg"]), json.loads(lmeta["schedule"])
+    lam = lambda e: orc.linear_schedule_factor(e, sch["num_warmup_steps"], sch["num_training_steps"])
+    prod = lr_lambda(sch["name"], sch["num_warmup_steps"], sch["num_training_steps"])
+    for k in range(cfg["steps"]):
+        assert abs(cfg["lr_unet"] * lam(k + 1) - lin["lrs"][k, 0].item()) < 1e-15
+        assert abs(cfg["lr_embed"] * lam(k + 1) - lin["lrs"][k, 1].item()) < 1e-15
+        assert lam(k + 1) == prod(k + 1)
+    unet, te = build_pti_models(t, cfg)
+    params, _ = orc.inject(unet, r=4)
+    with torch.no_grad():
+        for p, v in zip(params, torch.split(t["lora.init"], [q.numel() for q in params])):
+            p.copy_(v.view(p.shape))
+    table = orc.freeze_all_but_token_embeddings(te)
+    losses = orc.pti_tuning_steps(unet, te, params, cfg["steps"], cfg["batch"], cfg["latent_hw"], cfg["ctx_len"], cfg["vocab"],
+                                  lr_unet=cfg["lr_unet"], lr_embed=cfg["lr_embed"], weight_decay=cfg["weight_decay"],
+                                  v_prediction=cfg["v_prediction"], t_multiplier=cfg["t_multiplier"], lr_schedule=lam)
+    assert relerr(torch.tensor(losses), lin["losses"]) < 1e-5
+    assert relerr(orc.flat_params(params) - t["lora.init"], lin["lora.final"] - t["lora.init"]) < 1e-3
+    assert relerr(orc.flat_params(params), lin["lora.final"]) < 2e-5
+    assert relerr(table.detach() - t["table.init"], lin["table.final"] - t["table.init"]) < 1e-3
+    # and it is a different trajectory from the constant-rate one (the fixture pins the schedule, not only the loop)
+    assert relerr(lin["lora.final"] - t["lora.init"], t["lora.final"] - t["lora.init"]) > 0.2

@@ -8,7 +8,44 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from diffusion_finetuning_amd.trainer import LossScaler, SlabExchange
+from diffusion_finetuning_amd.trainer import SCHEDULER_NAMES, LoraTrainer, LossScaler, SlabExchange, lr_lambda
+
+
+@pytest.mark.parametrize("name", SCHEDULER_NAMES)
+def test_lr_lambda_inside_torch_lambdalr_gives_the_schedules_the_trainers_ask_for(name):
+    """`lr_lambda(name, warm-up, total)` under torch's LambdaLR (the mechanism get_scheduler wraps,
+    train_lora_dreambooth.py:737-743): ramp over the warm-up steps, then the named decay; and the two placements of
+    `lr_scheduler.step()` the reference has — after the optimizer (train_lora_dreambooth.py:885-886: step k at λ(k)) and
+    before it (cli_lora_pti.py:434: step k at λ(k + 1)) — as LoraTrainer._scheduled_lr_factor walks them."""
+    warm, total, base = 3, 12, 2e-4
+    lam = lr_lambda(name, warm, total, lr_init=base)
+    p = torch.nn.Parameter(torch.zeros(2))
+    opt = torch.optim.AdamW([p], lr=base)
+    sch = torch.optim.lr_scheduler.LambdaLR(opt, lam)
+    seen = []
+    for k in range(total + 2):
+        seen.append(sch.get_last_lr()[0])
+        opt.step()
+        sch.step()
+    assert all(abs(v - base * lam(k)) < 1e-18 for k, v in enumerate(seen))
+    assert [lam(k) for k in range(warm)] == ([1.0] * warm if name == "constant" else [k / warm for k in range(warm)])
+    assert lam(warm) == pytest.approx(1.0)
+    if name in ("linear", "cosine", "cosine_with_restarts"):
+        assert lam(total) == pytest.approx(0.0, abs=1e-12) and all(lam(k) >= lam(k + 1) for k in range(warm, total))
+    if name == "linear":
+        assert lam(warm + 3) == pytest.approx(1.0 - 3.0 / (total - warm))
+    for first in (False, True):
+        tr_ = LoraTrainer.__new__(LoraTrainer)  # the schedule bookkeeping alone (no device)
+        tr_.lr_lambda, tr_.scheduler_steps_first, tr_.scheduler_epoch = lam, first, 0
+        got = [tr_._scheduled_lr_factor() for _ in range(5)]
+        assert got == [lam(k + 1 if first else k) for k in range(5)] and tr_.scheduler_epoch == 5
+
+
+def test_lr_lambda_rejects_what_get_scheduler_rejects():
+    with pytest.raises(ValueError):
+        lr_lambda("exponential")
+    with pytest.raises(ValueError):
+        lr_lambda("linear", 0, None)  # needs num_training_steps
 
 
 def test_loss_scaler_applies_flags_at_a_fixed_lag():
