@@ -180,8 +180,11 @@ class LoraSlab:
             layer.__dict__["_dfa_grad_sink"] = sink
 
     # -- grouped projections ---------------------------------------------------------------------
-    def enable_groups(self):
-        """Finds the attention modules under the slab's models and groups their LoRA projections (groups.py): to_q/to_k/
+    def enable_groups(self, split_ctx_at: Sequence[str] = ()):
+        """(split_ctx_at: name prefixes — e.g. ("down_blocks.",) — whose cross-attentions get a K/V group of their OWN instead
+        of joining the model-wide one: the gradients of the other group are then final as soon as backward has left ITS
+        blocks, which is what an early exchange bucket needs — LoraTrainer(early_bucket=True).)
+        Finds the attention modules under the slab's models and groups their LoRA projections (groups.py): to_q/to_k/
         to_v of a self-attention into a QKVGroup, to_k/to_v of all cross-attentions over the same context width into a
         CtxKVGroup.  The groups are used by the attention forward installed with the reference's attention switch
         (attention.py); a model whose attention runs through its own forward never looks at them."""
@@ -201,7 +204,8 @@ class LoraSlab:
                 # BasicTransformerBlock gives its cross-attention in every version the reference supports)
                 is_cross = (m.to_k.linear.in_features != m.to_q.linear.in_features) or name.split(".")[-1] == "attn2"
                 if is_cross:
-                    key = (m.to_k.linear.in_features, m.to_k.lora_down.weight.shape[0])
+                    key = (m.to_k.linear.in_features, m.to_k.lora_down.weight.shape[0],
+                           next((pre for pre in split_ctx_at if name.startswith(pre)), ""))
                     cross.setdefault(key, []).append(m)
                 elif QKVGroup.eligible(trio):
                     grp = QKVGroup(trio, [self._sinks[index_of[id(l)]] for l in trio])
@@ -596,7 +600,7 @@ class LoraTrainer:
                  v_prediction=False, process_group=None, always_reduce=False, capture_graph=False,
                  group_projections=True, lr_embed: float = 5e-4, weight_decay_embed: Optional[float] = None,
                  lr_scheduler: str = "constant", lr_warmup_steps: int = 0, max_train_steps: Optional[int] = None,
-                 scheduler_steps_first: bool = False):
+                 scheduler_steps_first: bool = False, early_bucket: bool = False):
         """capture_graph: record add_noise → [text encoder] → UNet forward → loss → backward → factor gradients of a step
         once into a hipGraph and replay it on later steps with the same shapes (inputs are copied into static buffers).
         The gradient exchange and the optimizer stay outside the graph, so no collective is ever captured.  A step with a
@@ -617,6 +621,7 @@ class LoraTrainer:
         recorded step anyway.  The schedule counts step() calls; under accelerate a GradScaler-skipped step holds the scheduler
         back (AcceleratedScheduler), which matters for none of the reference's fp16 defaults ("constant"; PTI has no scaler)."""
         self.unet, self.text_encoder = unet, text_encoder
+        self.early_bucket = bool(early_bucket)
         self.lr_lambda = lr_lambda(lr_scheduler, lr_warmup_steps, max_train_steps, lr_init=lr)
         self.scheduler_steps_first = bool(scheduler_steps_first)
         self.scheduler_epoch = 0  # calls of lr_scheduler.step() so far (LambdaLR.last_epoch)
@@ -629,7 +634,11 @@ class LoraTrainer:
         self.trains_text_encoder = len(models) > 1 or train_emb
         self.slab = LoraSlab(models, [emb.weight] if train_emb else [])
         if group_projections:
-            self.slab.enable_groups()
+            # early_bucket: the cross-attentions of the down blocks project their K/V in a launch of their own, so that the
+            # [up|mid] part of the slab is final when backward leaves the mid block (the bucket hook below) — the price of
+            # an early exchange bucket WITH grouped projections: one more projection launch per pass, one more P-only
+            # launch in backward
+            self.slab.enable_groups(split_ctx_at=("down_blocks.",) if self.early_bucket else ())
         groups = [{"range": self.slab.model_ranges[0], "lr": lr, "weight_decay": weight_decay}]
         if len(models) > 1:
             groups.append({"range": self.slab.model_ranges[1], "lr": lr_text, "weight_decay": weight_decay})
@@ -691,8 +700,15 @@ class LoraTrainer:
         30-ms step.  DESIGN.md §6.)"""
         mid = getattr(self.unet, "mid_block", None)
         ups = getattr(self.unet, "up_blocks", None)
-        if mid is None or ups is None or self.slab.ctx_groups:
+        if mid is None or ups is None:
             return
+        if self.slab.ctx_groups and not self.early_bucket:
+            return  # one model-wide K/V group: its gradients come out of one launch at the very end of backward
+        inside = {id(l) for l in lora_layers(ups)} | {id(l) for l in lora_layers(mid)}
+        for grp in self.slab.ctx_groups:  # a group must lie entirely inside or entirely outside the early bucket
+            member = [id(l) in inside for l in grp.layers]
+            if any(member) and not all(member):
+                return
         a0, a1 = self.slab.range_of(ups)
         b0, b1 = self.slab.range_of(mid)
         if a1 != b0 or a1 <= a0:

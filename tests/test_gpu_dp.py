@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, batch, out, graph=False):
+def _run(rank, world, port, batch, out, graph=False, early_groups=False):
     import itertools
 
     import diffusion_finetuning_amd as dfa
@@ -33,7 +33,18 @@ def _run(rank, world, port, batch, out, graph=False):
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
-    unet = build_tiny_unet(seed=3).to(dev)
+    ctx_dim = 32
+    if early_groups:  # three levels, 64-wide context: two cross-attentions in the down blocks, four in [up|mid] — groupable
+        from diffusion_finetuning_amd.attention import set_use_memory_efficient_attention_xformers
+        from harness.unet import UNet2DConditionModel, tiny_config
+
+        torch.manual_seed(3)
+        unet = UNet2DConditionModel(tiny_config(64, 64, 3))
+        unet.requires_grad_(False)
+        unet = unet.to(dev)
+        ctx_dim = 64
+    else:
+        unet = build_tiny_unet(seed=3).to(dev)
     params, _ = dfa.inject_trainable_lora(unet, r=4)
     plist = list(itertools.chain(*params))
     g = torch.Generator().manual_seed(11 + rank)  # ranks start DIFFERENT: the broadcast must fix that
@@ -41,14 +52,30 @@ def _run(rank, world, port, batch, out, graph=False):
         for i, p in enumerate(plist):
             if i % 2 == 0:
                 p.copy_((torch.randn(p.shape, generator=g) * 0.02).to(dev))
-    trainer = tr.LoraTrainer(unet, lr=1e-3, group_projections=False, capture_graph=graph)  # ungrouped: the bucketed exchange is in play
+    if early_groups:
+        # grouped projections AND an early bucket: the down blocks' cross-attentions get a K/V group of their own, so the
+        # [up|mid] range of the slab is final — launched, folded, all-reduced — while backward is still in the down blocks
+        set_use_memory_efficient_attention_xformers(unet, True)
+        trainer = tr.LoraTrainer(unet, lr=1e-3, group_projections=True, early_bucket=True)
+        assert len(trainer.slab.ctx_groups) == 2 and len(trainer.slab.qkv_groups) > 0
+        names = {id(m): n for n, m in unet.named_modules()}
+        sides = [{names[id(m)].split(".")[0] for m in g.modules} for g in trainer.slab.ctx_groups]
+        assert sorted(map(sorted, sides)) == [["down_blocks"], ["mid_block", "up_blocks"]]
+        sent = []
+        send = trainer.exchange._send
+        trainer.exchange._send = lambda a, b: (sent.append((a, b)), send(a, b))[1]
+    else:
+        trainer = tr.LoraTrainer(unet, lr=1e-3, group_projections=False, capture_graph=graph)  # ungrouped: the bucketed exchange is in play
     if world > 1:
         assert trainer.exchange.active and trainer.exchange.early_range is not None
         assert trainer.exchange.single == graph  # a requested recording pins the exchange to ONE all-reduce per step
     for step in range(3):
-        latents, noise, ts, ctx = orc.synthetic_batch(step, batch * world, 8, 6, 32)
+        latents, noise, ts, ctx = orc.synthetic_batch(step, batch * world, 8, 6, ctx_dim)
         sl = slice(rank * batch, (rank + 1) * batch)
         trainer.step(latents[sl].to(dev), noise[sl].to(dev), ts[sl].to(dev), ctx[sl].to(dev))
+    if early_groups and world > 1:  # every step: the early [up|mid] bucket first (from the hook), then the rest of the slab
+        a0, b1 = trainer.exchange.early_range
+        assert b1 == trainer.slab.numel and sent == [(a0, b1), (0, a0), (b1, b1)] * 3, sent
     if graph:
         assert trainer._graph is not None  # the steps really were replays
     state = trainer.slab.params[: trainer.slab.numel].cpu()
@@ -74,6 +101,30 @@ def test_two_ranks_equal_one_rank_with_double_batch():
         p.join(timeout=300)
         assert p.exitcode == 0
     single = ctx.Process(target=_run, args=(0, 1, port, 4, q))
+    single.start()
+    one = torch.from_numpy(q.get(timeout=300))
+    single.join(timeout=300)
+    assert single.exitcode == 0
+    err = ((two - one).norm() / one.norm()).item()
+    assert err < 1e-4, err
+
+
+def test_two_ranks_with_grouped_projections_and_an_early_bucket_equal_one_rank_with_double_batch():
+    """LoraTrainer(early_bucket=True): the context K/V group is cut by block range, so WITH grouped
+    projections the [up|mid] bucket is exchanged from the mid block's backward hook while the down blocks still run backward
+    (reference: DDP's buckets fire inside backward, train_lora_dreambooth.py:744-757,877) — 2 ranks × batch 2 equal 1 rank
+    × batch 4, replicas identical, the bucket sequence is [early, head of the slab] on every step."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, 2, port, 2, q, False, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    two = torch.from_numpy(q.get(timeout=300))
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    single = ctx.Process(target=_run, args=(0, 1, port, 4, q, False, True))
     single.start()
     one = torch.from_numpy(q.get(timeout=300))
     single.join(timeout=300)
