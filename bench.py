@@ -54,6 +54,7 @@ def parse():
                     help="timed oracle steps of cpu_baseline.same_resolution (~3 s each on 16 cores; cfg1 always runs its 10)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --shared-gpu rehearses N ranks on one GPU")
     ap.add_argument("--shared-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--exchange-probe", action="store_true", help="only the 1-rank RCCL exchange probe (extra.exchange_probe)")
     ap.add_argument("--stub-body", default=None, choices=["ok", "fail", "diverge"],
                     help="test hook: ranks only rendezvous over gloo on the CPU and rank 0 prints a stub JSON line "
                          "('fail': rank 1 exits non-zero) — exercises the launcher without a GPU")
@@ -565,6 +566,65 @@ def run_workload(args, cfg_id, rank, world, device, dist, profile=True):
     return res
 
 
+def exchange_probe(args, device):
+    """VERDICT r4 N1 — the exchange against the compute around it, on ONE GPU through a 1-rank RCCL group (`always_reduce`: the
+    all-reduce calls, their stream hand-offs and their kernels are real; no bytes cross a link).  Three forms of the config-2
+    step, each on a fresh model: (a) the default — recorded step, ONE whole-slab all-reduce behind the replay; (b) host-launched,
+    one all-reduce after backward; (c) host-launched with `early_bucket=True` — the context K/V group cut by block range, the
+    [up|mid] bucket all-reduced from the mid block's backward hook while the down blocks still run backward (DDP's buckets fire
+    inside backward: train_lora_dreambooth.py:744-757,877).  Reported per form: ms/step (median of 7) and the device time of the
+    step's TAIL, from the end of backward to the re-packed factors (what the exchange adds to is in there)."""
+    import torch.distributed as dist
+
+    from diffusion_finetuning_amd.trainer import LoraTrainer
+
+    if dist.is_initialized():
+        return {"skipped": "a process group is already alive"}
+    cfg = CONFIGS[2]
+    dtype = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[args.dtype]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=device)
+    out = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "slab_MB": None,
+           "note": "1-rank RCCL group on one GPU: collective calls and kernels are real, nothing crosses xGMI"}
+    try:
+        data = synthetic_steps(3, cfg["batch"], cfg["latent"], 0, 1, device, cfg["ctx_len"], cfg["ctx_dim"], 1)
+        forms = (("recorded_single_allreduce", True, False), ("host_single_allreduce", False, False),
+                 ("host_early_bucket", False, True))
+        for name, graph, early in forms:
+            unet = build_unet(device, dtype, cfg["rank"], cfg["unet"])
+            trainer = LoraTrainer(unet, None, lr=1e-4, capture_graph=graph, always_reduce=True, early_bucket=early)
+            assert trainer.exchange.active
+            out["slab_MB"] = trainer.slab.numel * 4 / 1e6
+
+            def step(i):
+                lat, _, _, cond = data[i % len(data)]
+                return trainer.step(lat, None, None, seed=1000, encoder_hidden_states=cond)
+
+            for i in range(4):  # priming, recording, first replay
+                step(i)
+            times = []
+            for i in range(7):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                step(i)
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t)
+            trainer.tail_events = []
+            for i in range(5):
+                step(i)
+            torch.cuda.synchronize()
+            tails = sorted(a.elapsed_time(b) for a, b in trainer.tail_events)
+            trainer.tail_events = None
+            out[name] = {"ms_per_step": 1e3 * sorted(times)[len(times) // 2], "tail_ms_per_step": tails[len(tails) // 2],
+                         "collectives_per_step": 1 if not early else 2, "ctx_kv_groups": len(trainer.slab.ctx_groups),
+                         "replayed": bool(trainer._graph is not None)}
+            log(f"exchange probe [{name}]: {out[name]}")
+            del trainer, unet
+            torch.cuda.empty_cache()
+    finally:
+        dist.destroy_process_group()
+    return out
+
+
 def hot_path_summary(prof, steps, elapsed_prof):
     lora_ms = sum(v["ms"] for k, v in prof.items() if _is_lora_kind(k))
     all_ms = sum(v["ms"] for v in prof.values())
@@ -668,6 +728,9 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    if args.exchange_probe:
+        print(json.dumps({"metric": "exchange probe", "n_gpus": 1, "extra": {"exchange_probe": exchange_probe(args, device)}}), flush=True)
+        return
     if args.drop_in:  # only the unchanged-trainer route
         if rank == 0:
             print(json.dumps({"metric": "images/s SD1.5 LoRA rank-4 512^2 train step, unchanged reference trainer loop",
@@ -822,6 +885,12 @@ def main():
                     result["extra"] = {"drop_in": drop_in_route(args, device)}
                 except Exception as exc2:
                     result["extra"] = {"drop_in": {"error": repr(exc2)}}
+        if world == 1 and not args.no_extra and args.config == 2:
+            try:
+                result.setdefault("extra", {})["exchange_probe"] = exchange_probe(args, device)
+            except Exception as exc:  # (never at the headline's expense)
+                log(f"exchange probe failed: {exc!r}")
+                result.setdefault("extra", {})["exchange_probe"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:
             torch.cuda.empty_cache()
             result["cpu_baseline"] = cpu_baseline(CONFIGS[2]["rank"], CONFIGS[2]["latent"], args.cpu_steps)

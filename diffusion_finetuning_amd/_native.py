@@ -13,7 +13,7 @@ _LIB_PATH = os.environ.get("DFA_LIB_PATH") or os.path.join(os.path.dirname(os.pa
 _lib = None
 _lock = threading.Lock()
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 PROF_KINDS = 17
 
 _DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
@@ -58,6 +58,9 @@ SIGNATURES = {
     "lora_reduce_partials": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp]),
     "lora_grad_row_blocks": (_i32, [_i64]),
     "lora_grad_batched": (_i32, [ctypes.POINTER(GradProblem), _i32, _i32, _vp]),
+    "lora_grad_plan_bytes": (_i64, [ctypes.POINTER(GradProblem), _i32]),
+    "lora_grad_plan": (_i32, [ctypes.POINTER(GradProblem), _i32, _i32, _vp, _i64, ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
+    "lora_grad_planned": (_i32, [_vp, _i32, _i32, _i32, ctypes.c_double, ctypes.c_double, _vp]),
     "lora_fold_partials": (_i32, [_vp, _i32, _i64, _vp, _i64, _vp, _i32, _vp]),
     "lora_gemm_packed": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _f32,
                                 _i64, _vp, _i64, _i32, _vp]),
@@ -348,6 +351,46 @@ def lora_grad_batched(problems, dtype: torch.dtype, device) -> None:
     arr = (GradProblem * n)(*problems)
     stream = _raw_stream(device.index) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream
     _check(lib().lora_grad_batched(arr, n, dtype_code(dtype), stream), "lora_grad_batched")
+
+
+def lora_grad_plan_bytes(problems) -> int:
+    n = len(problems)
+    return int(lib().lora_grad_plan_bytes((GradProblem * n)(*problems), n)) if n else 0
+
+
+def lora_grad_one_launch(problems, dtype: torch.dtype, device, host_plan=None):
+    """All problems in ONE launch through a plan in device memory (include/lora_hip.h: lora_grad_plan / lora_grad_planned).
+    host_plan: a pinned uint8 tensor to write the plan into (a recording hands over a buffer it owns — the copy node reads it
+    on every replay); None allocates one (host-launched steps: torch's pinned allocator keeps the block until the copy has
+    run).  Returns the (host, device) plan tensors — the caller keeps them alive until the launch has run (a recording: for
+    its life) — or None when the library declines (fp32 / unaligned operands / rank > 16: use lora_grad_batched)."""
+    n = len(problems)
+    if n == 0 or dtype == torch.float32:
+        return None
+    arr = (GradProblem * n)(*problems)
+    need = int(lib().lora_grad_plan_bytes(arr, n))
+    if host_plan is None:
+        host_plan = torch.empty(need, dtype=torch.uint8, pin_memory=True)
+    elif host_plan.numel() < need or not host_plan.is_pinned():
+        return None
+    n_items, n_blocks = _i32(0), _i32(0)
+    st = lib().lora_grad_plan(arr, n, dtype_code(dtype), host_plan.data_ptr(), host_plan.numel(), ctypes.byref(n_items),
+                              ctypes.byref(n_blocks))
+    if st == -5:
+        return None
+    _check(st, "lora_grad_plan")
+    used = n_items.value * 128 + n_blocks.value * 4
+    if used == 0:
+        return (host_plan, None)
+    dev_plan = torch.empty(used, dtype=torch.uint8, device=device)
+    dev_plan.copy_(host_plan[:used], non_blocking=True)
+    e = float(torch.empty(0, dtype=dtype).element_size())
+    nbytes = sum(e * q.M * q.C + 4.0 * q.M * q.r + 4.0 * q.r * q.C for q in problems)
+    flops = sum(2.0 * q.M * q.r * q.C for q in problems)
+    stream = _raw_stream(device.index) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream
+    _check(lib().lora_grad_planned(dev_plan.data_ptr(), n_items.value, n_blocks.value, dtype_code(dtype), nbytes, flops, stream),
+           "lora_grad_planned")
+    return (host_plan, dev_plan)
 
 
 def lora_fold_partials(ranges, n_ranges: int, max_len: int, partials, part_stride: int, grads, accumulate: bool) -> None:

@@ -19,6 +19,7 @@
 // rank columns of one problem may belong to several layers (grouped q/k/v: U is [M, 3r], three gA outputs).
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "attn_common.h"
@@ -195,7 +196,7 @@ constexpr int kTileLd = 64 + 16;
 // meet in one group with two different lq; this XOR keeps their four slots distinct in every group
 __device__ __forceinline__ int p_slot(int j, int lq) { return lq ^ ((4 - (j >> 2)) & 3); }
 template <typename T>
-__global__ __launch_bounds__(256) void lora_grad_mfma_kernel(const GradBatch p) {
+__device__ __forceinline__ void grad_mfma_body(const GradItem& q, const int local) {
     using F8 = typename Mma<T>::F8;
     __shared__ __attribute__((aligned(16))) T sPh[kChunkRows * 16];  // [32-row group][j][lq][8 rows in operand order]
     __shared__ __attribute__((aligned(16))) T sPl[kChunkRows * 16];
@@ -204,11 +205,6 @@ __global__ __launch_bounds__(256) void lora_grad_mfma_kernel(const GradBatch p) 
     __shared__ float sScale[2][16];  // [0][j]: 2^k of rank column j for this row block, [1][j]: 2^-k
     constexpr bool kScaleP = sizeof(typename Mma<T>::F8) == 16 && std::is_same<T, half_t>::value;
 
-    int it = 0;
-    for (int i = 1; i < p.n; ++i) it += ((int)blockIdx.x >= p.first_block[i]) ? 1 : 0;
-    it = __builtin_amdgcn_readfirstlane(it);
-    const GradItem& q = p.item[it];
-    const int local = blockIdx.x - p.first_block[it];
     const int strip = local % q.strips;
     const int rb = local / q.strips;
 
@@ -345,7 +341,7 @@ __global__ __launch_bounds__(256) void lora_grad_mfma_kernel(const GradBatch p) 
                     const int j = lq * 4 + e;
                     if (j < r) {
                         const int grp = j / q.rg, jl = j - grp * q.rg;
-                        float* G = q.out[grp] + part_off;
+                        float* G = (grp == 0 ? q.out[0] : grp == 1 ? q.out[1] : grp == 2 ? q.out[2] : q.out[3]) + part_off;  // (no indexed read: the item may live in SGPRs)
                         const float v = acc[f][e] * (kScaleP ? q.scale * sScale[1][j] : q.scale);
                         if (q.out_kn)
                             G[(int64_t)jl * q.C + c0 + c] = v;
@@ -356,6 +352,43 @@ __global__ __launch_bounds__(256) void lora_grad_mfma_kernel(const GradBatch p) 
             }
         }
     }
+}
+
+// One item as wave-uniform scalars: read through the CONSTANT address space (s_load into SGPRs), field by field — a plain
+// struct copy went through vector loads and a scratch image, and the body must not index `out[]` dynamically on the copy.
+__device__ __forceinline__ GradItem fetch_item(const GradItem* gp, int* first_block) {
+    typedef const __attribute__((address_space(4))) GradItem* ItemPtr;
+    ItemPtr cp = (ItemPtr)gp;
+    GradItem q;
+    q.S = cp->S; q.P = cp->P;
+    q.out[0] = cp->out[0]; q.out[1] = cp->out[1]; q.out[2] = cp->out[2]; q.out[3] = cp->out[3];
+    q.s_stride = cp->s_stride; q.part_stride = cp->part_stride;
+    q.p_stride = cp->p_stride; q.C = cp->C; q.r = cp->r; q.rg = cp->rg; q.out_kn = cp->out_kn; q.CL = cp->CL;
+    q.strips = cp->strips; q.rows_per_block = cp->rows_per_block; q.nb = cp->nb; q.scale = cp->scale; q.M = cp->M;
+    *first_block = (int)cp->pad_[0];
+    return q;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void lora_grad_mfma_kernel(const GradBatch p) {
+    int it = 0;
+    for (int i = 1; i < p.n; ++i) it += ((int)blockIdx.x >= p.first_block[i]) ? 1 : 0;
+    it = __builtin_amdgcn_readfirstlane(it);
+    int unused;
+    const GradItem q = fetch_item(&p.item[it], &unused);
+    grad_mfma_body<T>(q, (int)blockIdx.x - p.first_block[it]);
+}
+
+// The same kernel over a PLAN in device memory (lora_grad_plan / lora_grad_planned): every problem of a step in ONE launch —
+// the ≤ 28-problem launches above end on a tail each, and the last few of a step hold a few dozen workgroups (15 µs apiece for
+// next to no bytes).  plan = [n items of 128 bytes | one int per workgroup: its item]; an item carries its first workgroup id.
+template <typename T>
+__global__ __launch_bounds__(256) void lora_grad_mfma_planned_kernel(const GradItem* __restrict__ items,
+                                                                     const int* __restrict__ block_item) {
+    const int it = __builtin_amdgcn_readfirstlane(block_item[blockIdx.x]);
+    int first;
+    const GradItem q = fetch_item(items + it, &first);
+    grad_mfma_body<T>(q, (int)blockIdx.x - first);
 }
 
 // Unaligned / large-rank path: one thread per output element, serial over the row block.  Correct, not fast.
@@ -597,6 +630,92 @@ extern "C" int lora_grad_batched(const lora_grad_problem* problems, int n, int d
         case LORA_BF16: return run_problems<bf16_t>(problems, n, nb, s);
         default: return LORA_E_BADARG;
     }
+}
+
+// ---- one launch for all problems of a step ------------------------------------------------------------------------------
+namespace {
+template <typename T>
+int plan_problems(const lora_grad_problem* probs, int n, char* plan, int64_t plan_bytes, int* n_items, int* n_blocks) {
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    // biggest problems first: the launch ends on small workgroups instead of on the tail of a 1-MB-per-block problem
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        return (double)probs[a].M * probs[a].C > (double)probs[b].M * probs[b].C;
+    });
+    std::vector<GradItem> items;
+    items.reserve(n);
+    int64_t blocks = 0;
+    for (int oi = 0; oi < n; ++oi) {
+        const lora_grad_problem& g = probs[order[oi]];
+        if (g.M == 0) continue;
+        if (g.r > 16) return LORA_E_UNSUPPORTED;
+        GradItem q{};
+        q.S = g.S; q.P = g.P;
+        for (int k = 0; k < 4; ++k) q.out[k] = g.out[k];
+        q.s_stride = g.s_stride; q.part_stride = g.part_stride; q.p_stride = g.p_stride; q.C = g.C; q.r = g.r;
+        q.rg = g.rg; q.out_kn = g.out_kn; q.scale = g.scale; q.M = g.M;
+        if (!plan_item<T>(q, g.n_blocks > 0 ? g.n_blocks : plan_row_blocks(g.M))) return LORA_E_UNSUPPORTED;
+        q.pad_[0] = blocks;  // first workgroup of the item
+        blocks += (int64_t)q.strips * q.nb;
+        items.push_back(q);
+    }
+    if (blocks > (1 << 20)) return LORA_E_UNSUPPORTED;
+    const int64_t need = (int64_t)items.size() * (int64_t)sizeof(GradItem) + blocks * 4;
+    *n_items = (int)items.size();
+    *n_blocks = (int)blocks;
+    if (need > plan_bytes) return LORA_E_BADARG;
+    if (!items.empty()) std::memcpy(plan, items.data(), items.size() * sizeof(GradItem));
+    int* block_item = reinterpret_cast<int*>(plan + items.size() * sizeof(GradItem));
+    for (size_t i = 0; i < items.size(); ++i)
+        for (int b = 0; b < items[i].strips * items[i].nb; ++b) block_item[items[i].pad_[0] + b] = (int)i;
+    return LORA_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t lora_grad_plan_bytes(const lora_grad_problem* problems, int n) {
+    if (!problems || n < 1) return 0;
+    int64_t blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const lora_grad_problem& g = problems[i];
+        const int nb = g.n_blocks > 0 ? g.n_blocks : plan_row_blocks(g.M);
+        blocks += (int64_t)nb * ((g.C + 7) / 8);  // (an upper bound: at least 8 columns per strip)
+    }
+    return (int64_t)n * (int64_t)sizeof(GradItem) + blocks * 4;
+}
+
+extern "C" int lora_grad_plan(const lora_grad_problem* problems, int n, int dtype, void* plan_host, int64_t plan_bytes,
+                              int* n_items, int* n_blocks) {
+    if (!problems || n < 1 || !plan_host || !n_items || !n_blocks) return LORA_E_BADARG;
+    if (mfma_min_rank() > 4) return LORA_E_UNSUPPORTED;  // (A/B knob: the VALU kernels only exist in the table-in-arguments form)
+    for (int i = 0; i < n; ++i) {
+        const int st = check_problem(problems[i]);
+        if (st != LORA_OK) return st;
+    }
+    switch (dtype) {
+        case LORA_F16: return plan_problems<half_t>(problems, n, static_cast<char*>(plan_host), plan_bytes, n_items, n_blocks);
+        case LORA_BF16: return plan_problems<bf16_t>(problems, n, static_cast<char*>(plan_host), plan_bytes, n_items, n_blocks);
+        case LORA_F32: return LORA_E_UNSUPPORTED;
+        default: return LORA_E_BADARG;
+    }
+}
+
+extern "C" int lora_grad_planned(const void* plan_dev, int n_items, int n_blocks, int dtype, double bytes, double flops,
+                                 void* stream) {
+    if (n_items < 0 || n_blocks < 0) return LORA_E_BADARG;
+    if (n_items == 0 || n_blocks == 0) return LORA_OK;
+    if (!plan_dev || !aligned16(plan_dev)) return LORA_E_BADARG;
+    const GradItem* items = static_cast<const GradItem*>(plan_dev);
+    const int* block_item = reinterpret_cast<const int*>(items + n_items);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ProfWork work(bytes, flops);
+    switch (dtype) {
+        case LORA_F16: LORA_LAUNCH(PK_GRAD_R4, (lora_grad_mfma_planned_kernel<half_t>), dim3((unsigned)n_blocks), dim3(256), 0, s, items, block_item); break;
+        case LORA_BF16: LORA_LAUNCH(PK_GRAD_R4, (lora_grad_mfma_planned_kernel<bf16_t>), dim3((unsigned)n_blocks), dim3(256), 0, s, items, block_item); break;
+        default: return LORA_E_UNSUPPORTED;
+    }
+    LORA_LAUNCH_CHECK();
+    return LORA_OK;
 }
 
 extern "C" int lora_linear_bwd_params(const void* dY, const void* X, const float* T, const float* U,

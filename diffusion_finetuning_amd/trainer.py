@@ -15,6 +15,7 @@ and the optimizer is two launches over the slab.  Data parallelism is one proces
 `torch.distributed` (backend "nccl" = RCCL over xGMI); only the LoRA gradients (≈5 MB at rank 4) ever cross GPUs.
 """
 import math
+import os
 from typing import Iterable, List, Optional, Sequence, Tuple
 
 import torch
@@ -161,6 +162,9 @@ class LoraSlab:
         self.offsets = []
         self._pending, self._keep, self._ran = {}, [], {}
         self._range_tables = {}
+        # factor gradients of a pass in one launch (lora_grad_planned); off: <= 28 problems per launch (DFA_ONE_LAUNCH_GRADS=0: A/B knob)
+        self.one_launch_grads = os.environ.get("DFA_ONE_LAUNCH_GRADS", "1") != "0"
+        self._plan_need, self._recording_plans, self._recorded_plans = {}, {}, []
         self.layer_rows = {}  # layer index -> (rows M, dX produced) of its last backward (accounting: survey_work)
         self.qkv_groups, self.ctx_groups = [], []
         self.packed = None
@@ -335,7 +339,8 @@ class LoraSlab:
         if not self._pending:
             return
         for dt, problems in self._pending.items():
-            nat.lora_grad_batched(problems, dt, self.device)
+            if not self._launch_planned(problems, dt):
+                nat.lora_grad_batched(problems, dt, self.device)
         key = tuple(sorted(self._ran.items()))
         table = self._range_tables.get(key)
         if table is None:
@@ -344,6 +349,38 @@ class LoraSlab:
                                                max(r_[1] for r_ in rows))
         nat.lora_fold_partials(table[0], len(key), table[1], self.partials, self.stride, self.grads, True)
         self._pending, self._keep, self._ran = {}, [], {}
+
+    # -- all factor-gradient problems of a pass in ONE launch (a plan in device memory) -----------------------------
+    def prepare_recording(self):
+        """Call right before a step is recorded into a hipGraph (outside the capture): reserves the pinned host buffers the
+        recording's plan copies will read on EVERY replay.  They belong to that recording (`take_recording_plans`), never to
+        the slab: a host-launched step or a later recording must not be able to rewrite what an older recording replays."""
+        self._recording_plans = {dt: torch.empty(2 * need + 4096, dtype=torch.uint8, pin_memory=True)
+                                 for dt, need in self._plan_need.items()}
+        self._recorded_plans = []
+
+    def take_recording_plans(self):
+        plans, self._recorded_plans, self._recording_plans = self._recorded_plans, [], {}
+        return plans
+
+    def _launch_planned(self, problems, dt) -> bool:
+        if not self.one_launch_grads:
+            return False
+        host = None
+        if torch.cuda.is_current_stream_capturing():
+            host = self._recording_plans.pop(dt, None)  # one buffer per (recording, dtype): a second flush of the pass declines
+            if host is None:
+                return False
+        else:
+            self._plan_need[dt] = max(self._plan_need.get(dt, 0), nat.lora_grad_plan_bytes(problems))
+        plan = nat.lora_grad_one_launch(problems, dt, self.device, host)
+        if plan is None:
+            return False
+        if host is not None:
+            self._recorded_plans.append(plan)  # the recording's: its copy node reads plan[0] on every replay
+        else:
+            self._keep.append(plan)            # host-launched: until the next pass (the pinned allocator waits for the copy)
+        return True
 
     def detach_sinks(self):
         for layer in self.layers:
@@ -851,12 +888,18 @@ class LoraTrainer:
         ehs = self._conditioning(encoder_hidden_states, input_ids)
         loss = self._forward_backward(noisy, target, timesteps, ehs, with_prior_preservation, prior_loss_weight,
                                       self._raw_mask(mask, latents))
+        tail = self.tail_events
+        if tail is not None:  # (bench.py: what the step still has to do once backward has finished — with an early bucket its
+            tail.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))  # all-reduce is behind us)
+            tail[-1][0].record()
         self.exchange.finish()
         if self.token_table is not None:
             self.token_table.collect(self.pg, self.world if self.exchange.active else 1)
         self.opt.step(grad_mul=1.0 / (self.world * self.loss_scale), lr_mul=self._scheduled_lr_factor())
         self._watch_overflow()
         self.slab.repack()  # forwards outside step() (sampling, evaluation, saving merged weights) see the new factors
+        if tail is not None:
+            tail[-1][1].record()
         return loss
 
     # -- the same step with forward+backward replayed from a hipGraph -----------------------------------
@@ -921,6 +964,7 @@ class LoraTrainer:
                     for _ in range(2):
                         self._graph_body(st)
                 torch.cuda.current_stream().wait_stream(side)
+                self.slab.prepare_recording()  # pinned plan buffers the recording will own (never allocated inside it)
                 g = torch.cuda.CUDAGraph()
                 # With a process group alive, its watchdog thread polls HIP events every now and then; under the default
                 # "global" capture mode such a call from ANOTHER thread invalidates the recording (a race that shows up
@@ -929,6 +973,7 @@ class LoraTrainer:
                 with torch.cuda.graph(g, capture_error_mode=mode):
                     self._graph_body(st)
                 st["graph"] = g
+                st["grad_plans"] = self.slab.take_recording_plans()  # host + device plan of the one-launch factor gradients
                 # the (ids, gradient rows) buffers the RECORDING writes on every replay belong to the recording, not to the
                 # table: an eager step in between resets the table's list (begin_pass), a replay cannot refill it
                 st["token_pending"] = list(self.token_table._pending) if self.token_table is not None else None

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LORA_HIP_ABI_VERSION 7
+#define LORA_HIP_ABI_VERSION 8
 
 enum lora_dtype { LORA_F32 = 0, LORA_F16 = 1, LORA_BF16 = 2 };
 
@@ -243,6 +243,24 @@ typedef struct lora_grad_problem {
 } lora_grad_problem;
 int lora_grad_row_blocks(int64_t M);
 int lora_grad_batched(const lora_grad_problem* problems, int n, int dtype, void* stream);
+/*
+ * The same problems in ONE launch (16-bit operands, ranks <= 16): lora_grad_batched's launches of <= 28 problems each end on a
+ * tail, and the last few of a step hold a few dozen workgroups.  Here the table is a PLAN in device memory:
+ *     lora_grad_plan_bytes(problems, n)  upper bound of the plan's size in bytes;
+ *     lora_grad_plan(...)                writes the plan — [items: 128 bytes per problem | one int per workgroup] — into HOST
+ *                                        memory `plan_host` and returns the counts; the first
+ *                                        n_items·128 + n_blocks·4 bytes are what the device needs.  LORA_E_UNSUPPORTED (fp32
+ *                                        operands, an unaligned operand, a rank above 16): use lora_grad_batched;
+ *     lora_grad_planned(plan_dev, ...)   launches on a DEVICE copy of those bytes.  The caller makes that copy with its own
+ *                                        stream-ordered transfer (inside a recording it is a memcpy node whose host source the
+ *                                        caller keeps alive and unchanged for as long as the recording is replayed) — the
+ *                                        library still allocates and retains nothing.  bytes / flops: what lora_prof_* charge.
+ * Same arithmetic, same row-block partial layout, same fold as lora_grad_batched: bit-identical results.
+ */
+int64_t lora_grad_plan_bytes(const lora_grad_problem* problems, int n);
+int lora_grad_plan(const lora_grad_problem* problems, int n, int dtype, void* plan_host, int64_t plan_bytes, int* n_items,
+                   int* n_blocks);
+int lora_grad_planned(const void* plan_dev, int n_items, int n_blocks, int dtype, double bytes, double flops, void* stream);
 int lora_fold_partials(const int64_t* ranges, int n_ranges, int64_t max_len, const float* partials,
                        int64_t part_stride, float* grads, int accumulate, void* stream);
 

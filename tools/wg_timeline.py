@@ -32,6 +32,8 @@ def main():
     lib.lora_linear_fwd.argtypes = [vp] * 9 + [i64, ci, ci, ci, cf, ci, vp]
     lib.lora_pack_factors.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.lora_debug_stamps.argtypes = [vp, ci]
+    lib.lora_linear_geglu_fwd.argtypes = [vp] * 8 + [i64, ci, ci, ci, cf, ci, vp]
+    gated = "--geglu" in sys.argv  # N = 2·F: the `proj` forward with the gate in its epilogue
     args = [int(a) for a in sys.argv[1:] if a.lstrip("-").isdigit()]
     shapes = [tuple(args[i:i + 3]) for i in range(0, len(args), 3)] or [
         (16384, 320, 320), (4096, 640, 640), (16384, 320, 2560), (16384, 1280, 320), (1024, 1280, 1280)]
@@ -48,7 +50,13 @@ def main():
         st = torch.cuda.current_stream().cuda_stream
         assert lib.lora_pack_factors(a.data_ptr(), b.data_ptr(), ap.data_ptr(), bp.data_ptr(), K, N, 4, 1, st) == 0
 
+        out = torch.empty(M, N // 2, device=dev, dtype=torch.float16)
+
         def launch():
+            if gated:
+                assert lib.lora_linear_geglu_fwd(x.data_ptr(), w.data_ptr(), None, ap.data_ptr(), bp.data_ptr(), y.data_ptr(),
+                                                 out.data_ptr(), t.data_ptr(), M, K, N, 4, 1.0, 1, st) == 0
+                return
             rc = lib.lora_linear_fwd(x.data_ptr(), w.data_ptr(), None, a.data_ptr(), b.data_ptr(), ap.data_ptr(),
                                      bp.data_ptr(), y.data_ptr(), t.data_ptr(), M, K, N, 4, 1.0, 1, st)
             assert rc == 0
