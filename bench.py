@@ -16,7 +16,11 @@ import os
 import sys
 import time
 
-import torch
+# dmabuf IPC (RCCL / device-tensor sharing across the ranks of one node needs it on this driver): set before anything
+# initialises the GPU, also when the driver starts the ranks itself with torch.distributed.run
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
