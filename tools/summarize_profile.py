@@ -128,6 +128,34 @@ def pmc(fetch, write, out, mfma=None):
     print(json.dumps(res, indent=1))
 
 
+def sq(paths):
+    """SQ wait / active counters per hot-path kernel from one or more --pmc passes of bench.py: sums per kernel class and the
+    ratios that say what a wave's life goes to (SQ_* wave counters are in quad-cycles, MI355X_MICROARCH.md): WAIT_ANY / WAVE_CYCLES
+    = share spent on s_waitcnt (operands in flight), WAIT_INST_ANY / WAVE_CYCLES = waiting for an issue slot."""
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    n = collections.defaultdict(int)
+    for path in paths:
+        seen = set()
+        for r in csv.DictReader(open(path)):
+            name = r["Kernel_Name"]
+            if not re.search(r"lora_|attn_|ddpm_", name):
+                continue
+            k = short(name)
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            key = (k, r.get("Dispatch_Id"))
+            if key not in seen:
+                seen.add(key)
+        for k, _ in seen:
+            n[k] += 1
+    print("# kernel class: dispatches (over the passes), counter sums, ratios to SQ_WAVE_CYCLES")
+    for k in sorted(agg, key=lambda k: -agg[k].get("SQ_WAVE_CYCLES", 0.0)):
+        v = agg[k]
+        wc = v.get("SQ_WAVE_CYCLES", 0.0)
+        ratios = {c.replace("SQ_", "") + "/WAVE": round(v[c] / wc, 3) for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+                                                                              "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS") if wc and c in v}
+        print(f"{k:52s} n={n[k]:5d} {ratios} " + " ".join(f"{c}={int(x)}" for c, x in sorted(v.items())))
+
+
 def shapes(path, warmup):
     """In-model time of every hot-path launch class: dispatches of the timed region grouped by (kernel, grid, LDS)."""
     rows = list(csv.DictReader(open(path)))
@@ -151,6 +179,8 @@ if __name__ == "__main__":
         shapes(sys.argv[2], int(sys.argv[3]))
     elif sys.argv[1] == "trace":
         trace(sys.argv[2], int(sys.argv[3]), sys.argv[4])
+    elif sys.argv[1] == "sq":
+        sq(sys.argv[2:])
     elif sys.argv[1] == "gaps":
         gaps(sys.argv[2], int(sys.argv[3]))
     else:
