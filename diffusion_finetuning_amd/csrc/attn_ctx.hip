@@ -67,26 +67,33 @@ template <typename T, int KS, int DF, int NKF> struct StageRegs {
 
 // softmax over the keys of one query row held as Sᵀ accumulators (lane = query l15; keys nf*16 + lq*4 + r).
 // In: raw scores.  Out: normalised probabilities in place; returns the row max (log2 domain) and 1/sum.
+// Round 5 (the kernels are bound by vector issue; this routine was 60 % of the forward loop's instructions): the scale rides in the
+// exponent's fma — p = exp2(fma(s, c, −c·max s)), c = scale·log2 e > 0, no separate multiply and subtract pass; the exponent is the bare
+// v_exp_f32 (arguments ≤ 0: the library exp2f's denormal-range fix-ups were a compare, an ldexp and two selects per score); keys
+// past Tk arrive masked: their scores START at −inf — key_mask() is the initial accumulator of the score chains (a per-lane constant,
+// built once per kernel: "row constants as the initial accumulator", here a key constant), so masking costs the loop nothing.
 template <int NKF>
-__device__ __forceinline__ void softmax_rows(f32x4 (&s)[NKF], int lq, int Tk, float scale_log2e, float& m, float& inv_l) {
-    m = -INFINITY;
+__device__ __forceinline__ void key_mask(f32x4 (&k0)[NKF], int lq, int Tk) {
 #pragma unroll
     for (int nf = 0; nf < NKF; ++nf)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = nf * 16 + lq * 4 + r;
-            const float v = key < Tk ? s[nf][r] * scale_log2e : -INFINITY;
-            s[nf][r] = v;
-            m = fmaxf(m, v);
-        }
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
+        for (int r = 0; r < 4; ++r) k0[nf][r] = nf * 16 + lq * 4 + r >= Tk ? -INFINITY : 0.f;
+}
+template <int NKF>
+__device__ __forceinline__ void softmax_rows(f32x4 (&s)[NKF], float scale_log2e, float& m, float& inv_l) {
+    float mr = -INFINITY;
+#pragma unroll
+    for (int nf = 0; nf < NKF; ++nf) mr = fmaxf(mr, fmaxf(fmaxf(s[nf][0], s[nf][1]), fmaxf(s[nf][2], s[nf][3])));
+    mr = fmaxf(mr, __shfl_xor(mr, 16, 64));
+    mr = fmaxf(mr, __shfl_xor(mr, 32, 64));
+    m = mr * scale_log2e;
+    const float nm = -m;
     float l = 0.f;
 #pragma unroll
     for (int nf = 0; nf < NKF; ++nf)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float p = exp2f(s[nf][r] - m);  // exp2f(-inf) = 0 for masked keys
+            const float p = __builtin_amdgcn_exp2f(fmaf(s[nf][r], scale_log2e, nm));  // exp2(−inf) = 0 for masked keys
             s[nf][r] = p;
             l += p;
         }
@@ -133,6 +140,8 @@ __global__ __launch_bounds__(256) void attn_ctx_fwd_kernel(const T* __restrict__
         const int t = chunk * rq + wave * 16 + l15;
         load_row_frags<T, KS>(Qh + (int64_t)t * HD, Qh, t < row_end, d, lq, qf);
     }
+    f32x4 kmask[NKF];
+    key_mask<NKF>(kmask, lq, Tk);
     for (int t0 = chunk * rq + wave * 16; t0 < row_end; t0 += 64) {
         const int t = t0 + l15;
         const bool valid = t < row_end;
@@ -142,7 +151,7 @@ __global__ __launch_bounds__(256) void attn_ctx_fwd_kernel(const T* __restrict__
         f32x4 s[NKF];
 #pragma unroll
         for (int nf = 0; nf < NKF; ++nf) {
-            s[nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            s[nf] = kmask[nf];  // 0, or −inf for keys past Tk
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const F8 kf = *reinterpret_cast<const F8*>(Ks + (nf * 16 + l15) * S::KROW + ks * 32 + lq * 8);
@@ -150,7 +159,7 @@ __global__ __launch_bounds__(256) void attn_ctx_fwd_kernel(const T* __restrict__
             }
         }
         float m, inv_l;
-        softmax_rows<NKF>(s, lq, Tk, scale_log2e, m, inv_l);
+        softmax_rows<NKF>(s, scale_log2e, m, inv_l);
 
         F8 pf[NKF / 2];
 #pragma unroll
@@ -216,6 +225,9 @@ __global__ __launch_bounds__(256, (ctx_bwd_occupancy<KS, DF, NKF>())) void attn_
         kr.store_rows(Ks);
         vr.store_rows(Vs);
     }
+    // key mask behind the staging area (the closing sum's overlay may run over it: it is dead by then)
+    float* kmask_s = reinterpret_cast<float*>(smem + (2 * S::NK * S::KROW + 4 * 2 * 16 * S::KROW + 4 * 2 * 16 * S::TROW) * 2);
+    if (threadIdx.x < S::NK) kmask_s[threadIdx.x] = (int)threadIdx.x >= Tk ? -INFINITY : 0.f;
     __syncthreads();
 
     f32x4 dk[NKF][DF], dv[NKF][DF];  // lane = head-dim column l15 of fragment df; keys nf*16 + lq*4 + r
@@ -251,7 +263,10 @@ __global__ __launch_bounds__(256, (ctx_bwd_occupancy<KS, DF, NKF>())) void attn_
         f32x4 s[NKF], dp[NKF];
 #pragma unroll
         for (int nf = 0; nf < NKF; ++nf) {
-            s[nf] = dp[nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // 0, or −inf for keys past Tk: the key mask as the initial accumulator (here from LDS — this kernel has no 24
+            // registers to spare at two workgroups per CU; one broadcast 16-byte read per fragment)
+            s[nf] = *reinterpret_cast<const f32x4*>(kmask_s + nf * 16 + lq * 4);
+            dp[nf] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int off = (nf * 16 + l15) * S::KROW + ks * 32 + lq * 8;
@@ -260,7 +275,7 @@ __global__ __launch_bounds__(256, (ctx_bwd_occupancy<KS, DF, NKF>())) void attn_
             }
         }
         float m, inv_l;
-        softmax_rows<NKF>(s, lq, Tk, scale_log2e, m, inv_l);
+        softmax_rows<NKF>(s, scale_log2e, m, inv_l);
         // P in the permuted key order, one row per query: re-read below with the keys along the lanes
 #pragma unroll
         for (int kk = 0; kk < NKF / 2; ++kk)
@@ -442,7 +457,7 @@ template <int KS, int DF, int NKF> constexpr int fwd_lds() {
 }
 template <int KS, int DF, int NKF> constexpr int bwd_lds() {
     using S = CtxShape<KS, DF, NKF>;
-    constexpr int stage = (2 * S::NK * S::KROW + 4 * 2 * 16 * S::KROW + 4 * 2 * 16 * S::TROW) * 2;
+    constexpr int stage = (2 * S::NK * S::KROW + 4 * 2 * 16 * S::KROW + 4 * 2 * 16 * S::TROW) * 2 + S::NK * 4;  // + key mask
     constexpr int F = 2 * NKF * DF, PH = (F + kCtxSumFrags - 1) / kCtxSumFrags, CH = (F + PH - 1) / PH;
     constexpr int red = 4 * CH * 64 * 16;  // four waves' images of one phase of the closing sum
     return stage > red ? stage : red;

@@ -564,10 +564,12 @@ struct RowStats {
         lse = ok ? lse_h[ok ? r : 0] : INFINITY;
         delta = ok ? delta_h[ok ? r : 0] : 0.f;
     }
+    // stored NEGATED: they are the initial accumulators −LSE / −Δ of the score and dP chains, and a negation per query block
+    // and wave is eight VALU instructions in a loop that is bound by vector issue
     __device__ __forceinline__ void store(float* lse_s, float* delta_s) const {
         if (threadIdx.x < 64) {
-            lse_s[threadIdx.x] = lse;
-            delta_s[threadIdx.x] = delta;
+            lse_s[threadIdx.x] = -lse;
+            delta_s[threadIdx.x] = -delta;
         }
     }
 };
@@ -632,17 +634,21 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
     stats.store(lse_s, delta_s);
     __syncthreads();
     const int n_tiles = (Tq + 63) / 64;
-    for (int qt = 0; qt < n_tiles; ++qt) {
+    // keys past Tk exist only in the last wave of the last workgroup of a ragged length: the masking of their probabilities
+    // (32 v_cndmask per query block when it sat in the one loop body — a sixth of its vector instructions, PMC: the kernel is
+    // bound by vector issue) lives in a second instantiation of the body that only such a wave runs (wave-uniform branch)
+    const bool keys_ragged = key0 + 16 * NKW > Tk;
+    auto query_tile = [&](int qt, auto ragged_tag) {
+        constexpr bool RAGGED = decltype(ragged_tag)::value;
         const int cur = qt & 1;
         const T* Qc = Qs + cur * S::K_HALFS;
         const T* Gc = Gs + cur * S::K_HALFS;
-        const float* lc = lse_s + cur * 64;
-        const float* dc = delta_s + cur * 64;
+        const float* lc = lse_s + cur * 64;   // −LSE (RowStats::store)
+        const float* dc = delta_s + cur * 64;  // −Δ
         if (qt + 1 < n_tiles) {
             stage.load(Qh + (int64_t)(qt + 1) * 64 * ldq, Gh + (int64_t)(qt + 1) * 64 * HD, Tq - (qt + 1) * 64);
             stats.load(lse_h, delta_h, (qt + 1) * 64, Tq);
         }
-        const bool keys_ragged = key0 + 16 * NKW > Tk;  // wave-uniform: only the last wave of the last workgroup
         if constexpr (PAIR) {
 #pragma unroll 1
             for (int qg = 0; qg < 2; ++qg) {  // 32 query rows at a time: two 16-row blocks fill one 32-deep MFMA contraction
@@ -661,7 +667,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
                     const f32x4 del4 = *reinterpret_cast<const f32x4*>(dc + r0 + hb * 16 + lq * 4);
 #pragma unroll
                     for (int nf = 0; nf < NKW; ++nf) {
-                        f32x4 s2 = -lse4, dp2 = -del4;  // row constants as the initial accumulators (see the dQ kernel)
+                        f32x4 s2 = lse4, dp2 = del4;  // row constants (−LSE, −Δ) as the initial accumulators (see the dQ kernel)
 #pragma unroll
                         for (int ks = 0; ks < KS; ++ks) {
                             s2 = Mma<T>::k32(qa[ks], kfr[nf][ks], s2);  // D[q][key]: lane = key, rows lq*4 + r
@@ -670,7 +676,9 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             float p = fast_exp2(s2[r]);
-                            if (keys_ragged && key0 + nf * 16 + l15 >= Tk) p = 0.f;
+                            if constexpr (RAGGED) {
+                                if (key0 + nf * 16 + l15 >= Tk) p = 0.f;
+                            }
                             pa[nf][hb * 4 + r] = from_f32<T>(p);
                             dsa[nf][hb * 4 + r] = from_f32<T>(p * dp2[r]);  // 1/√d goes onto dK at the end
                         }
@@ -711,7 +719,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
                 }
 #pragma unroll
                 for (int nf = 0; nf < NKW; ++nf) {
-                    f32x4 s2 = -lse4, dp2 = -del4;  // row constants as the initial accumulators (see the dQ kernel)
+                    f32x4 s2 = lse4, dp2 = del4;  // row constants (−LSE, −Δ) as the initial accumulators (see the dQ kernel)
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
                         s2 = Mma<T>::k32(qa[ks], kfr[nf][ks], s2);    // D[q][key]: lane = key, rows lq*4 + r
@@ -721,7 +729,9 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float p = fast_exp2(s2[r]);
-                        if (keys_ragged && key0 + nf * 16 + l15 >= Tk) p = 0.f;
+                        if constexpr (RAGGED) {
+                            if (key0 + nf * 16 + l15 >= Tk) p = 0.f;
+                        }
                         pa[r] = from_f32<T>(p);
                         dsa[r] = from_f32<T>(p * dp2[r]);  // 1/√d goes onto dK at the end
                     }
@@ -739,6 +749,11 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
             stats.store(lse_s + (cur ^ 1) * 64, delta_s + (cur ^ 1) * 64);
         }
         __syncthreads();
+    };
+    if (keys_ragged) {
+        for (int qt = 0; qt < n_tiles; ++qt) query_tile(qt, std::true_type{});
+    } else {
+        for (int qt = 0; qt < n_tiles; ++qt) query_tile(qt, std::false_type{});
     }
 #pragma unroll
     for (int nf = 0; nf < NKW; ++nf)
