@@ -206,19 +206,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
                  "s"(p.Nc), "s"(p.scale), "s"(p.tiles_m), "s"(p.tiles_n), "s"(p.col_major), "s"(p.lda), "s"(p.tile_part),
                  "s"(p.part_table), "s"(p.splitk), "s"(p.steps_per_slice), "s"(p.ws_c), "s"(p.ws_p), "s"(p.tickets), "s"(p.xcd_m),
                  "s"(p.split_aff));
-    // Persistent form (host: a grid SMALLER than the tile count, a multiple of 8 — launch_tile, LORA_PERSIST): a workgroup
-    // walks the tiles vb = blockIdx.x, blockIdx.x + gridDim.x, … — the XCD of a virtual id stays the XCD the block runs on
-    // (vb & 7 == blockIdx.x & 7), so the ownership maps below are unchanged; one barrier between tiles (LDS is re-used).
-    const int n_virtual = p.tiles_m * p.tiles_n * (SPLITK ? p.splitk : 1);
-    for (int vb = blockIdx.x; vb < n_virtual; vb += gridDim.x) {
-    if (vb != (int)blockIdx.x) __syncthreads();
-    sQ = smem + kStages * STAGE;
-    sP = reinterpret_cast<float*>(smem);
     int tile, slice = 0;
     {
         const int S = SPLITK ? p.splitk : 1;
         const int total = p.tiles_m * p.tiles_n * S;
-        const int id = vb;
+        const int id = blockIdx.x;
         const int q = total >> 3, rem = total & 7;
         const int xcd = id & 7, slot = id >> 3;
         tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
@@ -246,7 +238,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
         // Block id → (XCD, slot) as above; the XCD's rectangle is rm × rn tiles, walked column by column.
         const int xn = 8 / p.xcd_m;
         const unsigned rm = p.tiles_m / p.xcd_m, rn = p.tiles_n / xn;
-        const unsigned xcd = (unsigned)vb & 7, slot = (unsigned)vb >> 3;
+        const unsigned xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         const unsigned ln = slot / rm, lm = slot - ln * rm;
         tm = (xcd / xn) * rm + lm;
         tn = (xcd % xn) * rn + ln;
@@ -1025,7 +1017,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
     }
     STAMP(8);
     STAMP_WALL(9);
-    }  // (tiles of this workgroup)
 }
 
 // Shape-agnostic path (unaligned sizes or r > 16): correct, not fast.  F/Q read as fp32 masters.
@@ -1184,19 +1175,6 @@ __global__ __launch_bounds__(256) void pack_items_kernel(const int64_t* table, c
     }
 }
 
-// Grid of a launch with `tiles` output tiles.  More tiles than the chip holds workgroups (two 4-wave workgroups per CU: 512)
-// run as 512 PERSISTENT workgroups that walk the tiles (the kernel's tile loop) instead of as that many short-lived ones:
-// no workgroup launch between a CU's tiles, and a tile's stores drain under the next tile's first loads.  Round 5, weights
-// cold (profiles/r05_gemm_persistent_tiles_ab.log): the 2560-tile `proj` forward at 16384 rows 70.0 → 65.5 µs gated,
-// 60.9 → 56.1 ungated, 16384×320×2560 52.3 → 50.5; two-round grids (1024–1280 tiles) −0…2 %; one-round grids untouched.
-// LORA_PERSIST=0 restores one workgroup per tile (A/B knob).
-int persistent_grid(int tiles, int nw) {
-    static const int env = [] { const char* e = getenv("LORA_PERSIST"); return e ? atoi(e) : 1; }();
-    if (env <= 0) return tiles;
-    const int grid = 256 * (nw == 4 ? 2 : 1) * env;  // (a multiple of 8: a virtual id keeps its block's XCD)
-    return tiles > grid ? grid : tiles;
-}
-
 template <typename T, int BM, int BN, bool MAIN, int STG, int NW = 4, int WM = 2>
 int launch_tile(GemmParams p, hipStream_t stream) {
     p.tiles_m = (int)((p.M + BM - 1) / BM);
@@ -1247,7 +1225,7 @@ int launch_tile(GemmParams p, hipStream_t stream) {
     }
     constexpr int prof_id = MAIN ? (BM >= 256 ? PK_GEMM_256x128 : (BM == 128 ? PK_GEMM_128x128 : PK_GEMM_64x64))
                                  : (BM == 128 ? PK_SKINNY_128 : PK_SKINNY_64);
-    LORA_LAUNCH(prof_id, kern, dim3(persistent_grid(p.tiles_m * p.tiles_n, NW)), dim3(NW * 64), lds, stream, p);
+    LORA_LAUNCH(prof_id, kern, dim3(p.tiles_m * p.tiles_n), dim3(NW * 64), lds, stream, p);
     LORA_LAUNCH_CHECK();
     return LORA_OK;
 }
@@ -1282,7 +1260,7 @@ int launch_gate_bn(GemmParams p, hipStream_t stream) {
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr != hipSuccess) return LORA_E_LAUNCH;
-    LORA_LAUNCH(PK_GEMM_128x128, kern, dim3(persistent_grid(p.tiles_m * p.tiles_n, 4)), dim3(256), lds, stream, p);
+    LORA_LAUNCH(PK_GEMM_128x128, kern, dim3(p.tiles_m * p.tiles_n), dim3(256), lds, stream, p);
     LORA_LAUNCH_CHECK();
     return LORA_OK;
 }
@@ -1306,7 +1284,7 @@ int launch_gate_bwd_bn(GemmParams p, hipStream_t stream) {
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr != hipSuccess) return LORA_E_LAUNCH;
-    LORA_LAUNCH(PK_GATED_BWD, kern, dim3(persistent_grid(p.tiles_m * p.tiles_n, 4)), dim3(256), lds, stream, p);
+    LORA_LAUNCH(PK_GATED_BWD, kern, dim3(p.tiles_m * p.tiles_n), dim3(256), lds, stream, p);
     LORA_LAUNCH_CHECK();
     return LORA_OK;
 }

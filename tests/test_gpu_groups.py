@@ -215,6 +215,45 @@ def test_one_launch_factor_gradients_equal_the_batched_launches_bit_for_bit(dtyp
                                     torch.float16, torch.device(DEV, 0)) is None
 
 
+@pytest.mark.parametrize("M,K,N,r", [(100, 64, 64, 6), (64, 64, 64, 6), (128, 64, 64, 8), (100, 64, 128, 6), (100, 192, 64, 6),
+                                     (1024, 64, 64, 8), (100, 128, 64, 6)])
+def test_part_wise_backward_on_64_wide_outputs_is_exact_and_reproducible(relerr, M, K, N, r):
+    """The part-wise backward-input (`lora_gemm_parts`, contraction = three runs) on 64×64 tiles — outputs 64 wide, contractions
+    of 3 to 9 K-steps: what the q/k/v groups of a narrow model launch.  Round 5 found this instantiation racy in a build whose
+    kernel body sat inside a tile loop (rows 16–31 / columns 2–3 of every fragment wrong, differently on every run, while every
+    other shape passed): each shape runs four times — bit-identical — and against float64."""
+    g = torch.Generator().manual_seed(7)
+    G, dtype = 3, torch.float16
+    Ws = [((torch.rand(N, K, generator=g) * 2 - 1) / K ** 0.5).to(dtype) for _ in range(G)]
+    As = [(torch.randn(r, K, generator=g) / r) for _ in range(G)]
+    Bs = [(torch.randn(N, r, generator=g) * 0.05) for _ in range(G)]
+    dY = torch.randn(M, G * N, generator=g).to(dtype).to(DEV)
+    params = torch.cat([t.reshape(-1) for pair in zip(Bs, As) for t in pair]).to(DEV)
+    fa, qb, fb, qa = 0, 16 * G * K, 16 * G * K + 16 * G * N, 16 * G * K + 32 * G * N
+    rows, po = [], 0
+    for i in range(G):
+        up_off, down_off = po, po + N * r
+        po += N * r + r * K
+        rows.append([down_off, 0, K, r, fa + i * 16 * K, K, qa + i * 16 * K, 16])
+        rows.append([up_off, 1, N, r, fb + i * N, G * N, qb + i * N * 16, 16])
+    packed = torch.zeros(32 * G * (K + N), dtype=dtype, device=DEV)
+    nat.lora_pack_items(torch.tensor(rows, dtype=torch.int64).to(DEV), len(rows), max(K, N), params, packed)
+    Fb, Qa = packed[fb:qa], packed[qa:]
+    Wt = torch.cat(Ws).to(DEV).t().contiguous()
+    ref = torch.zeros(M, K, dtype=torch.float64)
+    for i in range(G):
+        dy_i = dY[:, i * N:(i + 1) * N].double().cpu()
+        ref += dy_i @ Ws[i].double() + 0.7 * (dy_i @ Bs[i].to(dtype).double()) @ As[i].to(dtype).double()
+    outs = []
+    for _ in range(4):
+        dX = torch.full((M, K), float("nan"), dtype=dtype, device=DEV)
+        U = torch.full((M, G * r), float("nan"), device=DEV)
+        assert nat.lora_gemm_parts(dY, Wt, None, Fb, Qa, dX, U, G * r, M, G * N, K, r, G, True, 0.7)
+        outs.append(dX.clone())
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    assert relerr(outs[0], ref) < 1e-3, relerr(outs[0], ref)
+
+
 def test_pack_items_layouts():
     """lora_pack_items: per-layer [A16|At16], [Bt16|B16] and the block-diagonal q/k/v layout (rows = r, destinations
     offset, buffer zeroed once)."""
