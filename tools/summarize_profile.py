@@ -131,10 +131,13 @@ def pmc(fetch, write, out, mfma=None):
 def sq(paths):
     """SQ wait / active counters per hot-path kernel from one or more --pmc passes of bench.py: sums per kernel class and the
     ratios that say what a wave's life goes to (SQ_* wave counters are in quad-cycles, MI355X_MICROARCH.md): WAIT_ANY / WAVE_CYCLES
-    = share spent on s_waitcnt (operands in flight), WAIT_INST_ANY / WAVE_CYCLES = waiting for an issue slot."""
-    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    = share spent on s_waitcnt (operands in flight), WAIT_INST_ANY / WAVE_CYCLES = waiting for an issue slot.  Every pass collects
+    SQ_WAVE_CYCLES itself: a counter is divided by the wave cycles of ITS pass."""
+    sums = collections.defaultdict(lambda: collections.defaultdict(float))
+    ratio = collections.defaultdict(dict)
     n = collections.defaultdict(int)
     for path in paths:
+        agg = collections.defaultdict(lambda: collections.defaultdict(float))
         seen = set()
         for r in csv.DictReader(open(path)):
             name = r["Kernel_Name"]
@@ -142,18 +145,18 @@ def sq(paths):
                 continue
             k = short(name)
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-            key = (k, r.get("Dispatch_Id"))
-            if key not in seen:
-                seen.add(key)
+            seen.add((k, r.get("Dispatch_Id")))
         for k, _ in seen:
             n[k] += 1
-    print("# kernel class: dispatches (over the passes), counter sums, ratios to SQ_WAVE_CYCLES")
-    for k in sorted(agg, key=lambda k: -agg[k].get("SQ_WAVE_CYCLES", 0.0)):
-        v = agg[k]
-        wc = v.get("SQ_WAVE_CYCLES", 0.0)
-        ratios = {c.replace("SQ_", "") + "/WAVE": round(v[c] / wc, 3) for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
-                                                                              "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS") if wc and c in v}
-        print(f"{k:52s} n={n[k]:5d} {ratios} " + " ".join(f"{c}={int(x)}" for c, x in sorted(v.items())))
+        for k, v in agg.items():
+            wc = v.get("SQ_WAVE_CYCLES", 0.0)
+            for c, x in v.items():
+                sums[k][c] += x
+                if wc and c != "SQ_WAVE_CYCLES":
+                    ratio[k][c.replace("SQ_", "") + "/WAVE"] = round(x / wc, 3)
+    print("# kernel class: dispatches (over the passes), ratios to the SQ_WAVE_CYCLES of the counter's own pass, counter sums")
+    for k in sorted(sums, key=lambda k: -sums[k].get("SQ_WAVE_CYCLES", 0.0)):
+        print(f"{k:52s} n={n[k]:5d} {ratio[k]} " + " ".join(f"{c}={int(x)}" for c, x in sorted(sums[k].items())))
 
 
 def shapes(path, warmup):
