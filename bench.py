@@ -865,6 +865,10 @@ def main():
                      "lora_params": r["lora_params"], "final_loss": r["final_loss"], "overflow": r["overflow"],
                      "launch_mode_trial": r["launch_trial"], "tail_ms_per_step": r["tail_ms"],
                      "survey_MB_per_step": (r["survey"]["fwd_bytes"] + r["survey"]["bwd_bytes"]) / 1e6}
+                if c["v_prediction"]:
+                    # (say it wherever a v-prediction number is quoted)
+                    e["note"] = ("v-prediction target and add_noise use the DDPM scaled-linear schedule restated from the model's hub "
+                                 "config / diffusers, which is not part of the reference tree: parity unpinned for those constants")
                 if r["prof"]:
                     hp = hot_path_summary(r["prof"], args.steps, r["elapsed_prof"])
                     e["hot_path_ms"] = hp["kernel_ms_per_step"]
