@@ -364,7 +364,10 @@ def test_grouped_projections_at_the_ranks_of_configs_3_and_5(relerr, r):
     assert len(t_g.slab.qkv_groups) == 4 and all(g.wide and g.r == r for g in t_g.slab.qkv_groups)
     assert len(t_g.slab.ctx_groups) == 1 and t_g.slab.ctx_groups[0]._pass is not None
     _, want, lu = _train(False, True, dtype=torch.float16, r=r)
-    assert relerr(lg, lu) < 2e-3 and relerr(got, want) < 2e-3, (relerr(lg, lu), relerr(got, want))
+    # (measured, round 5, five boxes: 8.3e-4…8.6e-4 at r = 8, 1.6e-3…1.7e-3 at r = 16 — f16 trajectories of two tilings; a part-wise
+    #  kernel that mis-computes a fragment gives 3.1e-3 / 5.5e-3, which is how the round-5 tile-loop regression was caught)
+    bound = 2e-3 if r == 8 else 3e-3
+    assert relerr(lg, lu) < 2e-3 and relerr(got, want) < bound, (relerr(lg, lu), relerr(got, want))
     ref = _tiny64()
     ref_params, _ = orc.inject(ref, r=r)
     _warm(ref_params)
