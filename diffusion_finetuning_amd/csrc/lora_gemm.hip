@@ -642,7 +642,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void lora_gemm_kernel(Gem
                 *flag = last ? 1u : 0u;
             }
             __syncthreads();
-            if (*flag == 0u) return;
+            STAMP(14);  // (diagnostic build: slab stored, ticket drawn)
+            if (*flag == 0u) {
+                STAMP(8);
+                STAMP_WALL(9);
+                return;
+            }
             // (c) the last arriver: totals over the slices in index order (its own contribution included, from memory, so
             // that the order of the additions never depends on who came last).  EVERY load of a slab is an sc1 load.
             if constexpr (MAIN) {
@@ -1131,6 +1136,11 @@ SplitPlan plan_splitk(int64_t M, int Kc, int Nc, int esize) {
     if ((Nc & 7) != 0 || (Kc * esize) % kRowBytes != 0 || tiles128 >= 192) return off;
     if (env <= 0 && nk < 48) return off;
     int bm = tiles128 <= 96 ? 64 : 128;
+    // round 5 (profiles/r05_splitk_plan_sweep.log, weights cold): a split launch is paced by its MAIN LOOP — 74 % of the 48-µs
+    // 1024×10240→1280 launch, 0.67 µs per K-step at two workgroups per CU: the L1-fill bound of the unsplit kernels — not by the
+    // combine (slab store + ticket 2 µs, the last arriver's sum 3.7 µs).  So the longest contractions take the 128-row tile (0.65× the
+    // L1 bytes per flop) with more slices where that still fills the chip: 80 tiles × 6 slices, 58.2 → 53.5 µs.
+    if (tiles128 >= 64 && nk >= 128) bm = 128;
     if (env_bm == 64 || env_bm == 128) bm = env_bm;
     const int64_t tiles = bm == 64 ? tiles64 : tiles128;
     if (tiles > kTicketBytes / 4) return off;

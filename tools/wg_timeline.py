@@ -34,6 +34,10 @@ def main():
     lib.lora_debug_stamps.argtypes = [vp, ci]
     lib.lora_linear_geglu_fwd.argtypes = [vp] * 8 + [i64, ci, ci, ci, cf, ci, vp]
     gated = "--geglu" in sys.argv  # N = 2·F: the `proj` forward with the gate in its epilogue
+    splitk = "--splitk" in sys.argv  # long contractions: the launch cuts K into slices (workspace handed over); LORA_SPLIT_AFFINITY=0|1
+    lib.lora_linear_fwd_ws.argtypes = [vp] * 9 + [i64, ci, ci, ci, cf, ci, vp, i64, vp]
+    lib.lora_gemm_workspace_bytes.restype = i64
+    lib.lora_gemm_workspace_bytes.argtypes = [i64, ci, ci, ci]
     args = [int(a) for a in sys.argv[1:] if a.lstrip("-").isdigit()]
     shapes = [tuple(args[i:i + 3]) for i in range(0, len(args), 3)] or [
         (16384, 320, 320), (4096, 640, 640), (16384, 320, 2560), (16384, 1280, 320), (1024, 1280, 1280)]
@@ -52,7 +56,18 @@ def main():
 
         out = torch.empty(M, N // 2, device=dev, dtype=torch.float16)
 
+        ws = None
+        if splitk:
+            nb = lib.lora_gemm_workspace_bytes(M, K, N, 1)
+            assert nb > 0, "the library does not split this shape"
+            ws = torch.zeros(nb // 4 + 16, device=dev)
+
         def launch():
+            if splitk:
+                assert lib.lora_linear_fwd_ws(x.data_ptr(), w.data_ptr(), None, a.data_ptr(), b.data_ptr(), ap.data_ptr(),
+                                              bp.data_ptr(), y.data_ptr(), t.data_ptr(), M, K, N, 4, 1.0, 1, ws.data_ptr(),
+                                              ws.numel() * 4, st) == 0
+                return
             if gated:
                 assert lib.lora_linear_geglu_fwd(x.data_ptr(), w.data_ptr(), None, ap.data_ptr(), bp.data_ptr(), y.data_ptr(),
                                                  out.data_ptr(), t.data_ptr(), M, K, N, 4, 1.0, 1, st) == 0
@@ -72,6 +87,24 @@ def main():
         s = buf.reshape(8192, 16).astype(np.int64)
         live = s[:, 0] > 0
         s = s[live]
+        if splitk:
+            # slices that were NOT their tile's last arriver leave after the ticket (stamp 14): main loop, slab store + ticket,
+            # life; the last arrivers also add the slices and run the epilogue (stamps 5..8)
+            last = s[:, 5] > 0
+            wall0 = s[:, 0].min()
+            life = (s[:, 9] - s[:, 0]) / 100.0
+            kk = np.median((s[:, 8] - s[:, 1])[life > 0] / life[life > 0])
+            def med(v): return f"median {np.median(v):6.2f} p90 {np.percentile(v, 90):6.2f} max {v.max():6.2f}"
+            print(f"--- split-K {M}x{K}x{N} (affinity {os.environ.get('LORA_SPLIT_AFFINITY', '0')}): {len(s)} workgroups, {int(last.sum())} last "
+                  f"arrivers; kernel span {((s[:, 9] - wall0) / 100.0).max():.2f} us; starts up to {((s[:, 0] - wall0) / 100.0).max():.2f} us")
+            print(f"    to first stage landed   {med((s[:, 3] - s[:, 1]) / kk)}")
+            print(f"    main loop               {med((s[:, 4] - s[:, 3]) / kk)}")
+            print(f"    slab store + ticket     {med((s[:, 14] - s[:, 4]) / kk)}")
+            print(f"    life, other slices      {med(life[~last])}")
+            print(f"    last arriver: sum of the slices + packed P  {med(((s[:, 5] - s[:, 14]) / kk)[last])}")
+            print(f"    last arriver: rank step, C tile, stores     {med(((s[:, 8] - s[:, 5]) / kk)[last])}")
+            print(f"    life, last arrivers     {med(life[last])}")
+            continue
         n = len(s)
         wall0 = s[:, 0].min()
         start_us = (s[:, 0] - wall0) / 100.0
