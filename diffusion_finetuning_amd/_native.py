@@ -13,8 +13,8 @@ _LIB_PATH = os.environ.get("DFA_LIB_PATH") or os.path.join(os.path.dirname(os.pa
 _lib = None
 _lock = threading.Lock()
 
-ABI_VERSION = 8
-PROF_KINDS = 17
+ABI_VERSION = 9
+PROF_KINDS = 18
 
 _DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
@@ -105,6 +105,7 @@ SIGNATURES = {
     "attn_flash_bwd": (_i32, [_vp] * 10 + [_i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "lora_prof_enable": (_i32, [_i32]),
     "lora_prof_collect": (_i32, [ctypes.POINTER(ProfTotals)]),
+    "lora_prof_null_mode": (_i32, [_i32]),
     "lora_prof_kernel_name": (ctypes.c_char_p, [_i32]),
 }
 
@@ -830,6 +831,11 @@ def attn_flash_bwd(q, k, v, out, dout, lse, heads: int, scale: float):
 
 def prof_enable(capacity: int) -> None:
     _check(lib().lora_prof_enable(int(capacity)), "lora_prof_enable")
+
+
+def prof_null_mode(on: bool) -> None:
+    """Launch-floor mode: every profiled launch site dispatches an empty kernel of the same shape (timing only)."""
+    _check(lib().lora_prof_null_mode(1 if on else 0), "lora_prof_null_mode")
 
 
 def prof_collect():

@@ -430,7 +430,9 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
     xcd_block(bx, bh);
     const int b = bh / H, h = bh - b * H;
     const int64_t HD = (int64_t)H * d;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wave index as a SCALAR: `keys_ragged` below selects one of two instantiations of a loop that contains workgroup
+    // barriers; derived from threadIdx it would be a divergent value to hipcc and the branch an exec-masked one — ADVICE r5)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
     const T* Qh = Q + (int64_t)b * Tq * ldq + h * d;
     const T* Gh = dO + (int64_t)b * Tq * HD + h * d;

@@ -354,11 +354,10 @@ __device__ __forceinline__ void grad_mfma_body(const GradItem& q, const int loca
     }
 }
 
-// One item as wave-uniform scalars: read through the CONSTANT address space (s_load into SGPRs), field by field — a plain
-// struct copy went through vector loads and a scratch image, and the body must not index `out[]` dynamically on the copy.
-__device__ __forceinline__ GradItem fetch_item(const GradItem* gp, int* first_block) {
-    typedef const __attribute__((address_space(4))) GradItem* ItemPtr;
-    ItemPtr cp = (ItemPtr)gp;
+// One item as wave-uniform scalars, field by field — a plain struct copy went through vector loads and a scratch image, and
+// the body must not index `out[]` dynamically on the copy.  `cp`: a reference into the kernel-argument struct (already scalar
+// loads), or a CONSTANT-address-space pointer into the plan in device memory (s_load into SGPRs).
+template <typename ItemRef> __device__ __forceinline__ GradItem copy_item(ItemRef cp, int* first_block) {
     GradItem q;
     q.S = cp->S; q.P = cp->P;
     q.out[0] = cp->out[0]; q.out[1] = cp->out[1]; q.out[2] = cp->out[2]; q.out[3] = cp->out[3];
@@ -368,6 +367,12 @@ __device__ __forceinline__ GradItem fetch_item(const GradItem* gp, int* first_bl
     *first_block = (int)cp->pad_[0];
     return q;
 }
+// (only for a REAL device pointer: a by-value kernel argument has no constant-address-space address unless the optimizer
+// happens to elide its private copy — ADVICE r5)
+__device__ __forceinline__ GradItem fetch_item(const GradItem* gp, int* first_block) {
+    typedef const __attribute__((address_space(4))) GradItem* ItemPtr;
+    return copy_item((ItemPtr)gp, first_block);
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void lora_grad_mfma_kernel(const GradBatch p) {
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(256) void lora_grad_mfma_kernel(const GradBatch p) 
     for (int i = 1; i < p.n; ++i) it += ((int)blockIdx.x >= p.first_block[i]) ? 1 : 0;
     it = __builtin_amdgcn_readfirstlane(it);
     int unused;
-    const GradItem q = fetch_item(&p.item[it], &unused);
+    const GradItem q = copy_item(&p.item[it], &unused);  // (the table travels in the kernel arguments: plain reads)
     grad_mfma_body<T>(q, (int)blockIdx.x - p.first_block[it]);
 }
 
@@ -710,8 +715,8 @@ extern "C" int lora_grad_planned(const void* plan_dev, int n_items, int n_blocks
     hipStream_t s = static_cast<hipStream_t>(stream);
     ProfWork work(bytes, flops);
     switch (dtype) {
-        case LORA_F16: LORA_LAUNCH(PK_GRAD_R4, (lora_grad_mfma_planned_kernel<half_t>), dim3((unsigned)n_blocks), dim3(256), 0, s, items, block_item); break;
-        case LORA_BF16: LORA_LAUNCH(PK_GRAD_R4, (lora_grad_mfma_planned_kernel<bf16_t>), dim3((unsigned)n_blocks), dim3(256), 0, s, items, block_item); break;
+        case LORA_F16: LORA_LAUNCH(PK_GRAD_PLANNED, (lora_grad_mfma_planned_kernel<half_t>), dim3((unsigned)n_blocks), dim3(256), 0, s, items, block_item); break;
+        case LORA_BF16: LORA_LAUNCH(PK_GRAD_PLANNED, (lora_grad_mfma_planned_kernel<bf16_t>), dim3((unsigned)n_blocks), dim3(256), 0, s, items, block_item); break;
         default: return LORA_E_UNSUPPORTED;
     }
     LORA_LAUNCH_CHECK();

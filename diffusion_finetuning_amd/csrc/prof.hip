@@ -3,6 +3,7 @@
 // state in the library, guarded by a mutex, and inert unless enabled.  Start/stop events are attached to
 // the kernel dispatch itself (hipExtLaunchKernelGGL in LORA_LAUNCH), so a record is the kernel's own
 // duration on the caller's stream — the same quantity rocprofv3 --kernel-trace reports.
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -26,6 +27,7 @@ ProfState& prof() {
     return s;
 }
 thread_local double tl_bytes = 0.0, tl_flops = 0.0;
+std::atomic<bool> g_null_mode{false};
 
 const char* const kKernelNames[LORA_PROF_KINDS] = {
     "lora_gemm_kernel<*, 128, 128|160, true>", "lora_gemm_kernel<*, 256, 128, true>", "lora_gemm_kernel<*, 64, 64|128|160, true>",
@@ -34,7 +36,8 @@ const char* const kKernelNames[LORA_PROF_KINDS] = {
     "other",
     "geglu_linear_bwd: lora_gemm_kernel<*, 128, 128, GATE=2> (frozen ff.net.2 backward GEMM + GEGLU gate backward)",
     "attn_flash_fwd_kernel", "attn_flash_dq_kernel", "attn_flash_dkdv_kernel", "attn_ctx_fwd_kernel",
-    "attn_ctx_bwd_kernel (+ attn_ctx_reduce_kernel)", "lora_gemm_kernel<*, 64|128, 128, true> split-K (in-launch combine)"};
+    "attn_ctx_bwd_kernel (+ attn_ctx_reduce_kernel)", "lora_gemm_kernel<*, 64|128, 128, true> split-K (in-launch combine)",
+    "lora_grad_mfma_planned_kernel (every rank class of a pass in one launch)"};
 
 }  // namespace
 
@@ -55,6 +58,13 @@ bool lora_prof_acquire(int kernel_id, hipEvent_t* e0, hipEvent_t* e1) {
     *e0 = r.e0;
     *e1 = r.e1;
     return true;
+}
+
+bool lora_prof_null_on() { return g_null_mode.load(std::memory_order_relaxed); }
+
+extern "C" int lora_prof_null_mode(int on) {
+    g_null_mode.store(on != 0, std::memory_order_relaxed);
+    return LORA_OK;
 }
 
 extern "C" int lora_version(void) { return LORA_HIP_ABI_VERSION; }

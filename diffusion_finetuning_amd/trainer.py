@@ -37,6 +37,25 @@ def ddpm_tables(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, de
 SCHEDULER_NAMES = ("linear", "cosine", "cosine_with_restarts", "polynomial", "constant", "constant_with_warmup")
 
 
+def survey_bytes_flops(layers, esize: int = 2, contract: bool = False):
+    """SURVEY §8(d), "Algorithmic bytes / flops per unit", summed over `layers` = (M, K, N, r, has_bias, dx_ran, reads_context)
+    per LoRA linear (reference operator lora_diffusion/lora.py:49-50 and its autograd): forward e·(MK+NK+MN) + e·r(K+N)
+    (+ e·N bias), backward e·(MN+MK) + (e+4)·r(K+N) + [e·(NK+MK) when dX is needed]; flops 2MKN + 2Mr(K+N) forward,
+    [2MKN] + 4Mr(K+N) + [2Mr(K+N)] backward.  Every operand once per direction, whatever the kernels re-read.
+    contract: dX needed unless the layer reads the (frozen) encoder context and the step produced none — SURVEY's rule."""
+    e = float(esize)
+    fb = bb = ff = bf = 0.0
+    n = 0
+    for M, K, N, r, has_bias, dx_ran, reads_context in layers:
+        dx = (dx_ran or not reads_context) if contract else dx_ran
+        fb += e * (M * K + N * K + M * N) + e * r * (K + N) + (e * N if has_bias else 0.0)
+        bb += e * (M * N + M * K) + (e + 4.0) * r * (K + N) + (e * (N * K + M * K) if dx else 0.0)
+        ff += 2.0 * M * K * N + 2.0 * M * r * (K + N)
+        bf += (2.0 * M * K * N if dx else 0.0) + 4.0 * M * r * (K + N) + (2.0 * M * r * (K + N) if dx else 0.0)
+        n += 1
+    return {"layers": n, "fwd_bytes": fb, "bwd_bytes": bb, "fwd_flops": ff, "bwd_flops": bf}
+
+
 def lr_lambda(name: str, num_warmup_steps: int = 0, num_training_steps: Optional[int] = None, lr_init: float = 1.0):
     """λ(epoch): the factor the trainers' `get_scheduler(name, optimizer, num_warmup_steps, num_training_steps)` puts on every
     param group's learning rate after `epoch` calls of `lr_scheduler.step()` (train_lora_dreambooth.py:737-743 with `--lr_scheduler`
@@ -166,6 +185,10 @@ class LoraSlab:
         self.one_launch_grads = os.environ.get("DFA_ONE_LAUNCH_GRADS", "1") != "0"
         self._plan_need, self._recording_plans, self._recorded_plans = {}, {}, []
         self.layer_rows = {}  # layer index -> (rows M, dX produced) of its last backward (accounting: survey_work)
+        # layers whose input is the text encoder's output (diffusers names the cross-attention of a transformer block attn2):
+        # the ones SURVEY §8(a) a3 exempts from dX while the encoder is frozen
+        name_of = {id(m): n for model in self.models for n, m in model.named_modules()}
+        self.reads_context = [name_of.get(id(l), "").endswith(("attn2.to_k", "attn2.to_v")) for l in self.layers]
         self.qkv_groups, self.ctx_groups = [], []
         self.packed = None
         off = 0
@@ -297,22 +320,19 @@ class LoraSlab:
     def note_layer(self, index: int, rows: int, need_dx: bool):
         self.layer_rows[index] = (int(rows), bool(need_dx))
 
-    def survey_work(self, esize: int = 2):
+    def survey_work(self, esize: int = 2, contract: bool = False):
         """Algorithmic bytes / flops of the LoRA layers that ran in the last step, by SURVEY §8(d)'s per-layer formulas
-        (reference operator lora_diffusion/lora.py:49-50 and its autograd): forward e·(MK+NK+MN) + e·r(K+N) (+ e·N bias),
-        backward e·(MN+MK) + (e+4)·r(K+N) + [e·(NK+MK) when dX is produced]; flops 2MKN + 2Mr(K+N) forward,
-        [2MKN] + 4Mr(K+N) + [2Mr(K+N)] backward.  Every operand counted ONCE per direction, whatever the kernels re-read."""
-        e = float(esize)
-        fb = bb = ff = bf = 0.0
+        (`survey_bytes_flops`).  contract=False: a dX is counted where the step produced one; contract=True: SURVEY's own
+        accounting — a dX for every layer but the `attn2.to_k / to_v` of a frozen text encoder (§8(a) a3), which is how its
+        5 331 MB for config 2 come about (the step itself skips three more: the first block's q/k/v read a tensor nothing
+        trainable precedes — 32 MB less)."""
+        rows = []
         for i, (M, dx) in self.layer_rows.items():
             layer = self.layers[i]
             r, K = layer.lora_down.weight.shape
             N = layer.lora_up.weight.shape[0]
-            fb += e * (M * K + N * K + M * N) + e * r * (K + N) + (e * N if layer.linear.bias is not None else 0.0)
-            bb += e * (M * N + M * K) + (e + 4.0) * r * (K + N) + (e * (N * K + M * K) if dx else 0.0)
-            ff += 2.0 * M * K * N + 2.0 * M * r * (K + N)
-            bf += (2.0 * M * K * N if dx else 0.0) + 4.0 * M * r * (K + N) + (2.0 * M * r * (K + N) if dx else 0.0)
-        return {"layers": len(self.layer_rows), "fwd_bytes": fb, "bwd_bytes": bb, "fwd_flops": ff, "bwd_flops": bf}
+            rows.append((M, K, N, r, layer.linear.bias is not None, dx, self.reads_context[i]))
+        return survey_bytes_flops(rows, esize, contract)
 
     # -- factor gradients --------------------------------------------------------------------------
     def zero_grad(self):
@@ -379,7 +399,10 @@ class LoraSlab:
         if host is not None:
             self._recorded_plans.append(plan)  # the recording's: its copy node reads plan[0] on every replay
         else:
-            self._keep.append(plan)            # host-launched: until the next pass (the pinned allocator waits for the copy)
+            # host-launched: `_keep` is cleared at the end of this very flush, so what keeps the plan's buffers alive until the
+            # copy and the launch have run is the allocators' stream ordering (the device buffer is reused only by later work of
+            # this stream; the pinned allocator holds a block until the copy that reads it has completed)
+            self._keep.append(plan)
         return True
 
     def detach_sinks(self):
@@ -598,11 +621,14 @@ class TokenTable:
 
     def check_ids(self, input_ids):
         """torch.nn.Embedding raises on an id outside the table; the HIP gather cannot (it poisons the row with NaN, so the
-        step is skipped as an overflow).  Raise like torch wherever the check is free or cheap: ids still on the host, or a
-        host-launched pass (one small sync); never inside a stream capture."""
-        if input_ids.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+        step is skipped as an overflow).  Raise like torch where the check is FREE: ids still on the host.  Device-resident ids
+        are not looked at (the check was two blocking device-to-host syncs in every host-launched encoder pass, and
+        under data parallelism it raised on one rank only, leaving the others blocked in the next collective): for them the
+        NaN-poisoned row is the signal — the step is skipped like any overflow, on every rank alike, since the overflow flag is
+        computed on the all-reduced slab."""
+        if input_ids.device.type != "cpu" or not input_ids.numel():
             return
-        if input_ids.numel() and (int(input_ids.min()) < 0 or int(input_ids.max()) >= self.V):
+        if int(input_ids.min()) < 0 or int(input_ids.max()) >= self.V:
             raise IndexError(f"token id out of range for the {self.V}-row embedding table")
 
     def _forward(self, module, input_ids):
@@ -637,7 +663,7 @@ class LoraTrainer:
                  v_prediction=False, process_group=None, always_reduce=False, capture_graph=False,
                  group_projections=True, lr_embed: float = 5e-4, weight_decay_embed: Optional[float] = None,
                  lr_scheduler: str = "constant", lr_warmup_steps: int = 0, max_train_steps: Optional[int] = None,
-                 scheduler_steps_first: bool = False, early_bucket: bool = False):
+                 scheduler_steps_first: bool = False, early_bucket: bool = False, scheduler_steps_per_call: int = 1):
         """capture_graph: record add_noise → [text encoder] → UNet forward → loss → backward → factor gradients of a step
         once into a hipGraph and replay it on later steps with the same shapes (inputs are copied into static buffers).
         The gradient exchange and the optimizer stay outside the graph, so no collective is ever captured.  A step with a
@@ -655,13 +681,25 @@ class LoraTrainer:
         the dreambooth loop steps the scheduler AFTER the optimizer (:885-886: step k runs at λ(k), k = 0, 1, …), the PTI
         tuning loop BEFORE it (cli_lora_pti.py:434: step k runs at λ(k + 1) — with the default linear schedule the first step
         is already at lr·(1 − 1/N) and the last at 0).  The factor is a host scalar of the AdamW launch, which is outside a
-        recorded step anyway.  The schedule counts step() calls; under accelerate a GradScaler-skipped step holds the scheduler
-        back (AcceleratedScheduler), which matters for none of the reference's fp16 defaults ("constant"; PTI has no scaler)."""
+        recorded step anyway.
+        `scheduler_steps_per_call`: how far ONE `lr_scheduler.step()` of the trainer moves the schedule.  The
+        dreambooth script hands its scheduler to `accelerator.prepare` (train_lora_dreambooth.py:750-757), and accelerate's
+        AcceleratedScheduler steps the wrapped scheduler once PER PROCESS on every call (split_batches=False, the script's
+        default): on N GPUs the reference's non-constant schedules decay N times faster per optimizer step than on one.  Pass the
+        world size to reproduce that route; 1 (default) is a plain scheduler — cli_lora_pti.py (single process, no accelerate)
+        and the default "constant" schedule are unaffected either way.  accelerate is not in the reference tree nor importable
+        here: that N× rule is restated from its published AcceleratedScheduler, parity unpinned.  Not reproduced: accelerate
+        also holds the scheduler back on a step its GradScaler skipped — the skip is known here only two steps later
+        (LossScaler's fixed lag), so the schedule counts every step() call; it matters for none of the reference's fp16
+        defaults ("constant"; PTI has no scaler)."""
         self.unet, self.text_encoder = unet, text_encoder
         self.early_bucket = bool(early_bucket)
         self.lr_lambda = lr_lambda(lr_scheduler, lr_warmup_steps, max_train_steps, lr_init=lr)
         self.scheduler_steps_first = bool(scheduler_steps_first)
-        self.scheduler_epoch = 0  # calls of lr_scheduler.step() so far (LambdaLR.last_epoch)
+        self.scheduler_epoch = 0  # LambdaLR.last_epoch: scheduler steps taken so far
+        self.scheduler_steps_per_call = int(scheduler_steps_per_call)
+        if self.scheduler_steps_per_call < 1:
+            raise ValueError("scheduler_steps_per_call must be >= 1")
         self.capture_graph = bool(capture_graph)
         self._graph = None
         models = [unet] + ([text_encoder] if text_encoder is not None and lora_layers(text_encoder) else [])
@@ -804,11 +842,12 @@ class LoraTrainer:
 
     def _scheduled_lr_factor(self) -> float:
         """λ for the optimizer launch of this step, and the scheduler's own step() before or after it."""
+        n = self.scheduler_steps_per_call
         if self.scheduler_steps_first:
-            self.scheduler_epoch += 1
+            self.scheduler_epoch += n
             return float(self.lr_lambda(self.scheduler_epoch))
-        self.scheduler_epoch += 1
-        return float(self.lr_lambda(self.scheduler_epoch - 1))
+        self.scheduler_epoch += n
+        return float(self.lr_lambda(self.scheduler_epoch - n))
 
     def get_last_lr(self) -> List[float]:
         """`lr_scheduler.get_last_lr()` (what the trainers log, train_lora_dreambooth.py:959): one value per param group."""

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LORA_HIP_ABI_VERSION 8
+#define LORA_HIP_ABI_VERSION 9
 
 enum lora_dtype { LORA_F32 = 0, LORA_F16 = 1, LORA_BF16 = 2 };
 
@@ -464,7 +464,7 @@ int attn_flash_bwd(const void* Q, const void* K, const void* V, const void* O, c
  * returns a substring of that name.  lora_prof_collect waits for the recorded events, returns the totals
  * and resets the recording.
  */
-#define LORA_PROF_KINDS 17
+#define LORA_PROF_KINDS 18
 typedef struct lora_prof_totals {
     int64_t launches[LORA_PROF_KINDS];
     double ms[LORA_PROF_KINDS];
@@ -474,6 +474,13 @@ typedef struct lora_prof_totals {
 int lora_prof_enable(int capacity /* max recorded launches; 0 disables and frees */);
 int lora_prof_collect(lora_prof_totals* out);
 const char* lora_prof_kernel_name(int kind);
+/*
+ * Launch-floor mode (measurement only; bench.py's `roofline.step_level.launch_floor_ms`): while on, every profiled launch site
+ * dispatches an EMPTY kernel of the same signature — same grid, block, dynamic LDS and kernel-argument segment; it reads two
+ * argument words and returns — in place of the real one.  With the profiler enabled the recorded durations are then what a
+ * launch of that shape costs before it does any work.  Outputs are NOT written while the mode is on: timing only.
+ */
+int lora_prof_null_mode(int on);
 
 #ifdef __cplusplus
 }

@@ -111,3 +111,54 @@ def test_bench_workloads_follow_baseline_configs():
     g = torch.Generator().manual_seed(1000)
     want = torch.randn(4, 4, 64, 64, generator=g) * 0.18215
     assert torch.equal(bench.synthetic_steps(1, 4, 64, 0, 1, "cpu")[0][0], want)
+
+
+# the distinct LoRA linears of config 2 (SD1.5, batch 4, 64² latents, 77-token context) as (M, K, N, count)
+SURVEY_CFG2_LAYERS = [(16384, 320, 320, 30), (16384, 320, 2560, 5), (308, 768, 320, 10), (4096, 640, 640, 30), (4096, 640, 5120, 5),
+                      (308, 768, 640, 10), (1024, 1280, 1280, 30), (1024, 1280, 10240, 5), (308, 768, 1280, 12), (256, 1280, 1280, 6),
+                      (256, 1280, 10240, 1)]
+
+
+def test_contract_bytes_of_config_2_are_surveys_5331_mb():
+    """`roofline.step_level.algorithmic_MB_per_step_survey` is SURVEY §8(d)'s figure: 5 331 MB per step at config 2 (forward
+    2 359 + backward 2 972, a dX for every layer but the frozen encoder's attn2.to_k / to_v), whatever the step itself skips —
+    it skips the dX of the first block's q/k/v (their input has no trainable producer): 32 MB less, reported beside it."""
+    from diffusion_finetuning_amd.trainer import survey_bytes_flops
+
+    rows, skipped = [], 0
+    for M, K, N, count in SURVEY_CFG2_LAYERS:
+        ctx = K == 768
+        for _ in range(count):
+            first_qkv = (M, K, N) == (16384, 320, 320) and skipped < 3  # down_blocks.0 ... attn1.to_q/k/v
+            skipped += first_qkv
+            rows.append((M, K, N, 4, False, not ctx and not first_qkv, ctx))
+    assert len(rows) == 144
+    c = survey_bytes_flops(rows, 2, contract=True)
+    assert abs(c["fwd_bytes"] / 1e6 - 2358.8) < 0.1 and abs(c["bwd_bytes"] / 1e6 - 2972.3) < 0.1
+    assert abs((c["fwd_bytes"] + c["bwd_bytes"]) / 1e6 - 5331.1) < 0.1
+    ran = survey_bytes_flops(rows, 2)
+    assert abs((ran["fwd_bytes"] + ran["bwd_bytes"]) / 1e6 - 5299.0) < 0.3  # what rounds 4–5 reported as the contract
+    assert abs((c["fwd_flops"] + c["bwd_flops"]) / 1e9 - 1476) < 2  # SURVEY: 1 476 GF per step
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "survey_work(2 if args.dtype != \"f32\" else 4, contract=True)" in src  # the line's figure is the contract's
+
+
+def test_launch_floor_fields_of_the_roofline_object():
+    """`roofline.step_level` carries the measured launch floor (empty kernels at every hot-path launch site, in the step's order)
+    and the HBM fraction against the kernel time above that floor."""
+    import bench
+
+    gemm = "lora_gemm_kernel<*, 64, 64|128|160, true>"
+    roof = {"step_level": {"hbm_bound_ms": 0.666, "kernel_ms_per_step": 4.0},
+            "fused_gemm_classes": {gemm: {"launches_per_step": 110.0, "ms_per_step": 1.9}}}
+    floor = {gemm: {"launches": 110.0, "ms": 0.55}, "lora_grad_{mfma_,}kernel, ranks <= 4": {"launches": 1.0, "ms": 0.02},
+             "attn_flash_fwd_kernel": {"launches": 16.0, "ms": 0.1}}  # (attention kinds are not §8(d) layers)
+    bench.add_launch_floor(roof, floor, tot_ms=4.0)
+    sl = roof["step_level"]
+    assert abs(sl["launch_floor_ms"] - 0.57) < 1e-9 and sl["launch_floor_launches_per_step"] == 111.0
+    assert abs(sl["frac_vs_launch_bounded"] - 0.666 / (4.0 - 0.57)) < 1e-9
+    assert abs(sl["launch_floor_all_library_kinds_ms"] - 0.67) < 1e-9
+    assert abs(sl["frac_ceiling_with_per_layer_launches"] - 0.666 / (0.666 + 0.57)) < 1e-9
+    assert abs(roof["fused_gemm_classes"][gemm]["launch_floor_us_per_launch"] - 5.0) < 1e-9
+    bench.add_launch_floor(roof2 := {"step_level": {}}, {}, 4.0)  # no floor pass: nothing added, nothing raised
+    assert roof2 == {"step_level": {}}

@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_version_and_status_strings_without_gpu():
     lib = nat.lib()
-    assert lib.lora_version() == nat.ABI_VERSION == 8
+    assert lib.lora_version() == nat.ABI_VERSION == 9
     assert lib.lora_status_string(0) == b"ok"
     assert b"rank" in lib.lora_status_string(-2).lower()
     assert lib.lora_mse_workspace_bytes() >= 16 and lib.lora_sqnorm_workspace_bytes() >= 16

@@ -36,9 +36,25 @@ def test_lr_lambda_inside_torch_lambdalr_gives_the_schedules_the_trainers_ask_fo
         assert lam(warm + 3) == pytest.approx(1.0 - 3.0 / (total - warm))
     for first in (False, True):
         tr_ = LoraTrainer.__new__(LoraTrainer)  # the schedule bookkeeping alone (no device)
-        tr_.lr_lambda, tr_.scheduler_steps_first, tr_.scheduler_epoch = lam, first, 0
+        tr_.lr_lambda, tr_.scheduler_steps_first, tr_.scheduler_epoch, tr_.scheduler_steps_per_call = lam, first, 0, 1
         got = [tr_._scheduled_lr_factor() for _ in range(5)]
         assert got == [lam(k + 1 if first else k) for k in range(5)] and tr_.scheduler_epoch == 5
+    # the dreambooth route under accelerate on N processes — AcceleratedScheduler steps the wrapped scheduler N times
+    # per call (split_batches=False): optimizer step k runs at λ(N·k); restated here with torch's LambdaLR stepped N times
+    for world in (2, 8):
+        w = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([w], lr=base)
+        sch = torch.optim.lr_scheduler.LambdaLR(opt, lam)
+        want = []
+        for _ in range(4):
+            want.append(opt.param_groups[0]["lr"] / base)
+            opt.step()
+            for _ in range(world):
+                sch.step()
+        tr_ = LoraTrainer.__new__(LoraTrainer)
+        tr_.lr_lambda, tr_.scheduler_steps_first, tr_.scheduler_epoch, tr_.scheduler_steps_per_call = lam, False, 0, world
+        got = [tr_._scheduled_lr_factor() for _ in range(4)]
+        assert got == pytest.approx(want, abs=1e-15) and tr_.scheduler_epoch == 4 * world
 
 
 def test_lr_lambda_rejects_what_get_scheduler_rejects():
