@@ -48,3 +48,41 @@ def test_product_does_not_import_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_no_mfma_result_is_read_early_across_a_branch(tmp_path):
+    """hipcc pads the distance between an MFMA and the first vector instruction that reads its destination registers along
+    the LAYOUT order of the blocks only: a conditional branch that skips the padded block can land on a reader that comes
+    too early — what made round 5's persistent-tile build of the fused GEMM return rows 16–31 / columns 2–3 of a tile wrong,
+    differently on every run (tools/check_mfma_hazard.py).  Every kernel source is compiled to ISA and scanned."""
+    import subprocess
+    import sys
+    from concurrent.futures import ThreadPoolExecutor
+
+    from diffusion_finetuning_amd import build_native as bn
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_mfma_hazard as chk
+
+    srcs = [s for s in bn.SOURCES if s not in ("prof.hip", "optim.hip", "ddpm_loss.hip", "embed.hip")]  # (kernels with MFMAs)
+
+    def to_isa(src):
+        out = str(tmp_path / (src + ".s"))
+        subprocess.run([bn.HIPCC, *bn.FLAGS, *bn.SOURCE_FLAGS.get(src, []), "-S", "--cuda-device-only",
+                        os.path.join(bn.CSRC, src), "-o", out], check=True, capture_output=True)
+        return out
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        files = list(ex.map(to_isa, srcs))
+    findings = []
+    for f in files:
+        kernels = chk.parse(f)
+        assert kernels, f
+        findings += chk.check(kernels)
+    assert not findings, findings[:3]
+    # the checker itself: the hazard of the round-5 build, reduced to its shape, is found
+    bad = tmp_path / "bad.s"
+    bad.write_text("_Z3badv:\n\tv_mfma_f32_16x16x32_f16 v[2:5], v[40:43], v[36:39], v[16:19]\n\ts_cbranch_vccz .LBB0_2\n"
+                   "\ts_nop 6\n\tv_pk_add_f32 v[2:3], v[8:9], v[2:3]\n.LBB0_2:\n\ts_add_i32 s18, s9, s63\n"
+                   "\tv_cvt_pk_f16_f32 v5, v4, v5\n\ts_endpgm\n.Lfunc_end0:\n")
+    assert len(chk.check(chk.parse(str(bad)))) == 1
