@@ -12,14 +12,13 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "liblora_hip.so")
-SOURCES = ["lora_gemm.hip", "lora_grad.hip", "ddpm_loss.hip", "optim.hip", "sandwich.hip", "attn_ctx.hip", "attn_flash.hip",
-           "attn_flash_narrow.hip", "embed.hip", "prof.hip"]
+SOURCES = ["lora_gemm.hip", "lora_grad.hip", "ddpm_loss.hip", "optim.hip", "sandwich.hip", "attn_ctx.hip", "attn_flash.hip", "embed.hip", "prof.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
-# per-source flags.  attn_flash_narrow.hip runs at ONE wave per SIMD (512 registers); there hipcc gives every MFMA an
-# accumulation-register destination and copies each result out with v_accvgpr_read before the vector unit may touch it:
-# the VGPR form keeps the scores where the exponent reads them (its file header has the numbers).
-SOURCE_FLAGS = {"attn_flash_narrow.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+# per-source flags (none at present).  A kernel that runs at ONE wave per SIMD (> 256 registers) wants
+# ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]: there hipcc otherwise gives every MFMA an accumulation-register destination and copies each
+# result out with v_accvgpr_read before the vector unit may touch it (profiles/r06_attn_dkdv_one_wave_and_32x32_kernels_rejected.hip).
+SOURCE_FLAGS = {}
 
 
 def _digest() -> str:

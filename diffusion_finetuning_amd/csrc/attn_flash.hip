@@ -430,9 +430,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
     xcd_block(bx, bh);
     const int b = bh / H, h = bh - b * H;
     const int64_t HD = (int64_t)H * d;
-    // (the wave index as a SCALAR: `keys_ragged` below selects one of two instantiations of a loop that contains workgroup
-    // barriers; derived from threadIdx it would be a divergent value to hipcc and the branch an exec-masked one — ADVICE r5)
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     const T* Qh = Q + (int64_t)b * Tq * ldq + h * d;
     const T* Gh = dO + (int64_t)b * Tq * HD + h * d;
@@ -473,23 +471,21 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
     // loads of the resident V fragments into the loop as "pending" and puts an s_waitcnt vmcnt(0) in front of their first use in
     // EVERY query block — behind the tile loads, whose latency that wait then exposes on every tile (round 6, from the ISA)
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    // keys past Tk exist only in the last wave of the last workgroup of a ragged length: the masking of their probabilities
-    // (32 v_cndmask per query block when it sat in the one loop body — a sixth of its vector instructions, PMC: the kernel is
-    // bound by vector issue) lives in a second instantiation of the body that only such a wave runs (wave-uniform branch)
-    const bool keys_ragged = key0 + 16 * NKW > Tk;
-    auto query_tile = [&](int qt, auto ragged_tag) {
-        constexpr bool RAGGED = decltype(ragged_tag)::value;
+    // Keys past Tk (the last waves of the last workgroup of a ragged length) need NO masking here: a key's probabilities only
+    // enter ITS OWN rows of dK and dV (the key is the output row of both contractions), those rows are never stored, and their
+    // K / V fragments were loaded as zeros, so nothing non-finite can arise.  (Through round 5 a second instantiation of the loop
+    // body masked them — 32 v_cndmask per query block — behind a wave-uniform branch; ADVICE r5 flagged that branch.)
+    auto query_tile = [&](int qt) {
         const int cur = qt & 1;
         const T* Qc = Qs + cur * S::K_HALFS;
         const T* Gc = Gs + cur * S::K_HALFS;
         const float* lc = lse_s + cur * 64;   // −LSE (RowStats::store)
         const float* dc = delta_s + cur * 64;  // −Δ
         if (qt + 1 < n_tiles) {
-            // (the row statistics FIRST: their registers' previous loads were consumed under `threadIdx.x < 64`, so hipcc's wait
-            // bookkeeping still counts them as pending on the other waves' path and puts an s_waitcnt vmcnt(0) in front of the
-            // next write to them — behind the tile's 16-byte loads that wait exposed their whole latency on every tile)
-            stats.load(lse_h, delta_h, (qt + 1) * 64, Tq);
+            // (nothing here may make hipcc wait for these loads before the tile's arithmetic: TileStageS::load and RowStats —
+            // through round 5 an s_waitcnt vmcnt(0) sat right behind them and exposed their whole latency on every tile)
             stage.load(Qh + (int64_t)(qt + 1) * 64 * ldq, Gh + (int64_t)(qt + 1) * 64 * HD, Tq - (qt + 1) * 64);
+            stats.load(lse_h, delta_h, (qt + 1) * 64, Tq);
         }
         if constexpr (PAIR) {
 #pragma unroll 1
@@ -517,10 +513,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
                         }
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            float p = fast_exp2(s2[r]);
-                            if constexpr (RAGGED) {
-                                if (key0 + nf * 16 + l15 >= Tk) p = 0.f;
-                            }
+                            const float p = fast_exp2(s2[r]);
                             pa[nf][hb * 4 + r] = from_f32<T>(p);
                             dsa[nf][hb * 4 + r] = from_f32<T>(p * dp2[r]);  // 1/√d goes onto dK at the end
                         }
@@ -570,10 +563,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
                     T pa[4], dsa[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float p = fast_exp2(s2[r]);
-                        if constexpr (RAGGED) {
-                            if (key0 + nf * 16 + l15 >= Tk) p = 0.f;
-                        }
+                        const float p = fast_exp2(s2[r]);
                         pa[r] = from_f32<T>(p);
                         dsa[r] = from_f32<T>(p * dp2[r]);  // 1/√d goes onto dK at the end
                     }
@@ -592,11 +582,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
         }
         __syncthreads();
     };
-    if (keys_ragged) {
-        for (int qt = 0; qt < n_tiles; ++qt) query_tile(qt, std::true_type{});
-    } else {
-        for (int qt = 0; qt < n_tiles; ++qt) query_tile(qt, std::false_type{});
-    }
+    for (int qt = 0; qt < n_tiles; ++qt) query_tile(qt);
 #pragma unroll
     for (int nf = 0; nf < NKW; ++nf)
 #pragma unroll
@@ -713,12 +699,6 @@ int launch_flash_bwd(const FlashBwdArgs& a, hipStream_t stream) {
                     a.delta, static_cast<T*>(a.dQ), a.Tq, a.Tk, a.H, a.d, a.scale, l2e, a.ldq, a.ld_dq);
         lora_prof_set_work(0.0, 0.0);
         LORA_LAUNCH_CHECK();
-    }
-    if constexpr (KS == 2 && DF == 3) {
-        // narrow heads: FLASH_NARROW=1 selects the one-wave-per-SIMD kernel of attn_flash_narrow.hip (measured, round 6: 278 µs
-        // against 269 for the two-wave form below at 4096 tokens — profiles/README.md)
-        static const int narrow_env = [] { const char* e = getenv("FLASH_NARROW"); return e ? atoi(e) : 0; }();
-        if (narrow_env) return lora_flash_dkdv_narrow(a, ElemTraits<T>::kDtype, stream);
     }
     {
         constexpr int lds = flash_dkdv_lds<KS, DF>();

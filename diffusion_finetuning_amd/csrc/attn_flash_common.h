@@ -1,12 +1,12 @@
-// Definitions shared by the long-context attention kernels (attn_flash.hip: every head width; attn_flash_narrow.hip: the
-// backward of heads of at most 48 channels at one wave per SIMD).
+// Definitions shared by the long-context attention kernels (attn_flash.hip; round 6 also built two alternative dK / dV kernels on
+// them, measured and kept under profiles/r06_attn_dkdv_one_wave_and_32x32_kernels_rejected.hip).
 #pragma once
 #include <cstdlib>
 #include <type_traits>
 
 #include "attn_common.h"
 
-// Arguments of the backward launches (shared with attn_flash_narrow.hip, a translation unit of its own)
+// Arguments of the backward launches
 struct LoraFlashBwdArgs {
     const void *Q, *K, *V, *O, *dO;
     const float* LSE;
@@ -16,8 +16,6 @@ struct LoraFlashBwdArgs {
     float scale;
     int64_t ldq, ld_dq;  // row strides shared by Q/K/V and by dQ/dK/dV
 };
-// dK / dV of heads of at most 48 channels at one wave per SIMD (attn_flash_narrow.hip); Δ must have been written (dQ launch)
-int lora_flash_dkdv_narrow(const LoraFlashBwdArgs& a, int dtype, hipStream_t stream);
 
 namespace {
 
@@ -55,71 +53,86 @@ __device__ __forceinline__ u32x4 load16_or_zero(const void* p, bool ok) {
     return ok ? v : u32x4{0u, 0u, 0u, 0u};
 }
 
-template <typename T, int KS, int DF> struct TileStage {
-    using S = FlashShape<KS, DF>;
+template <typename T, typename S> struct TileStageS {  // S: a shape with KROW (halfs per LDS row) and IT (16-byte chunks per thread)
     // (raw 128-bit registers, not element arrays: with 16-bit ELEMENTS on the ragged path hipcc merges the two paths of
     // load() element-wise and re-packs every chunk with v_alignbit / v_perm right behind its load — an s_waitcnt vmcnt
     // that exposes the whole load latency on every tile)
     u32x4 a[S::IT], b[S::IT];
-    int64_t src[S::IT];           // element offset of the chunk inside tile 0 of A
-    int dld;                      // row stride of B minus row stride of A (uniform): B's offset = src + row·dld
-    int row[S::IT], rowoff[S::IT];  // row; offset in a row-major [64][KROW] tile
-    bool have[S::IT];
+    // ONE register of map per chunk — row | column << 8, row 255 = the thread has no such chunk — and the two row strides: the
+    // offsets are two multiply-adds per chunk and tile.  (Round 5 kept row, LDS offset, 64-bit source offset and a flag per
+    // chunk: 5 registers each; the kernels that use this sit at the 256-register limit of two waves per SIMD, and a spilled
+    // address comes back through a scratch load — which counts in vmcnt: the wait for it also waits for the tile loads just
+    // issued.)  64·lda fits 31 bits (checked by the entry points), so the in-tile source offset is an int.
+    int rc[S::IT];
+    int lda_, ldb_;
+#ifdef FLASH_ABL_NOSTAGE
+    bool staged_once = false;
+#endif
+    __device__ __forceinline__ bool have(int i) const { return (rc[i] & 255) != 255; }
+    __device__ __forceinline__ int row(int i) const { return rc[i] & 255; }
+    __device__ __forceinline__ int col(int i) const { return rc[i] >> 8; }
     __device__ __forceinline__ void init(int d, int64_t lda, int64_t ldb) {
         const int cpr = d >> 3, n = kTile * cpr;
-        dld = (int)(ldb - lda);
+        lda_ = (int)lda;
+        ldb_ = (int)ldb;
 #pragma unroll
         for (int i = 0; i < S::IT; ++i) {
             const int idx = threadIdx.x + i * 256;
-            have[i] = idx < n;
-            const int r = have[i] ? idx / cpr : 0, c = have[i] ? (idx - r * cpr) * 8 : 0;
-            row[i] = r;
-            src[i] = (int64_t)r * lda + c;
-            rowoff[i] = r * S::KROW + c;
+            const int r = idx / cpr, c = (idx - r * cpr) * 8;
+            rc[i] = idx < n ? (r | (c << 8)) : 255;
         }
     }
-    // A, B: first row of the tile in each tensor; rows_valid >= 64 for a full tile
+    // A, B: first row of the tile in each tensor; rows_valid >= 64 for a full tile.
+    // Every load issued before this call must have been consumed (it is: a tile's chunks go to LDS before the barrier that ends
+    // the tile).  The explicit wait states that to hipcc: the chunks are stored under `have(i)`, so on the other lanes' path its
+    // wait bookkeeping still counts the previous tile's loads as pending, and depending on the register allocation it then puts
+    // an s_waitcnt vmcnt(0) BETWEEN this tile's loads or behind them (round 6: +30 µs on the 4096-token dK/dV launch when a
+    // one-line change elsewhere moved two address registers) — nothing is in flight here, so this wait costs nothing.
     __device__ __forceinline__ void load(const T* A, const T* B, int rows_valid) {
+#ifdef FLASH_ABL_NOSTAGE  // diagnostic builds only (timing; results are wrong): every tile after the first re-uses tile 0's rows
+        if (staged_once) return;
+        staged_once = true;
+#endif
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         if (rows_valid >= kTile) {
 #pragma unroll
             for (int i = 0; i < S::IT; ++i) {
-                const int64_t off = have[i] ? src[i] : 0;
-                int rr = have[i] ? row[i] : 0;
-                asm volatile("" : "+v"(rr));  // recompute rr·dld at every tile: hoisted out of the loop it costs registers
-                a[i] = *reinterpret_cast<const u32x4*>(A + off);
-                b[i] = *reinterpret_cast<const u32x4*>(B + off + rr * dld);
+                const int r = have(i) ? row(i) : 0, c = have(i) ? col(i) : 0;
+                a[i] = *reinterpret_cast<const u32x4*>(A + (r * lda_ + c));
+                b[i] = *reinterpret_cast<const u32x4*>(B + (r * ldb_ + c));
             }
         } else {
 #pragma unroll
             for (int i = 0; i < S::IT; ++i) {
-                const bool ok = have[i] && row[i] < rows_valid;
-                const int64_t off = ok ? src[i] : 0;
-                int rr = ok ? row[i] : 0;
-                asm volatile("" : "+v"(rr));
-                a[i] = load16_or_zero(A + off, ok);
-                b[i] = load16_or_zero(B + off + rr * dld, ok);
+                const bool ok = have(i) && row(i) < rows_valid;
+                const int r = ok ? row(i) : 0, c = ok ? col(i) : 0;
+                a[i] = load16_or_zero(A + (r * lda_ + c), ok);
+                b[i] = load16_or_zero(B + (r * ldb_ + c), ok);
             }
         }
     }
     __device__ __forceinline__ void store_a_rows(T* dst) const {
 #pragma unroll
         for (int i = 0; i < S::IT; ++i)
-            if (have[i]) *reinterpret_cast<u32x4*>(dst + rowoff[i]) = a[i];
+            if (have(i)) *reinterpret_cast<u32x4*>(dst + row(i) * S::KROW + col(i)) = a[i];
     }
     __device__ __forceinline__ void store_b_rows(T* dst) const {
 #pragma unroll
         for (int i = 0; i < S::IT; ++i)
-            if (have[i]) *reinterpret_cast<u32x4*>(dst + rowoff[i]) = b[i];
+            if (have(i)) *reinterpret_cast<u32x4*>(dst + row(i) * S::KROW + col(i)) = b[i];
     }
     // both tiles without a branch: a thread's chunks beyond the tile go to `dump` (16 bytes of LDS of its own)
     __device__ __forceinline__ void store_rows_unmasked(T* dst_a, T* dst_b, T* dump) const {
 #pragma unroll
         for (int i = 0; i < S::IT; ++i) {
-            *reinterpret_cast<u32x4*>(have[i] ? dst_a + rowoff[i] : dump) = a[i];
-            *reinterpret_cast<u32x4*>(have[i] ? dst_b + rowoff[i] : dump) = b[i];
+            const int off = row(i) * S::KROW + col(i);
+            *reinterpret_cast<u32x4*>(have(i) ? dst_a + off : dump) = a[i];
+            *reinterpret_cast<u32x4*>(have(i) ? dst_b + off : dump) = b[i];
         }
     }
 };
+template <typename T, int KS, int DF> using TileStage = TileStageS<T, FlashShape<KS, DF>>;
+
 
 // zero `bytes` of LDS (multiple of 16) cooperatively: the padding columns / rows of the tiles stay zero for the kernel's life
 __device__ __forceinline__ void lds_zero(char* base, int bytes) {
@@ -187,26 +200,25 @@ __device__ __forceinline__ void prescale_frags(typename Mma<T>::F8 (&f)[KS], flo
 
 // LSE and Δ of one 64-row query tile: threads 0..63 carry one row each (+inf / 0 past the end: probability 0)
 struct RowStats {
-    float lse, delta;
+    float lse, delta;  // as loaded (a valid row's, whatever `ok` says)
+    bool ok;
+    // No predicated load and no select behind the load (either would make hipcc wait for it on the spot): the row index is
+    // clamped, and rows past the end get their +inf / 0 when the values go to LDS
     __device__ __forceinline__ void load(const float* lse_h, const float* delta_h, int row0, int Tq) {
         const int r = row0 + (int)(threadIdx.x & 63);
-        const bool ok = r < Tq;
-        lse = ok ? lse_h[ok ? r : 0] : INFINITY;
-        delta = ok ? delta_h[ok ? r : 0] : 0.f;
+        ok = r < Tq;
+        const int rr = ok ? r : Tq - 1;
+        lse = lse_h[rr];
+        delta = delta_h[rr];
     }
     // stored NEGATED: they are the initial accumulators −LSE / −Δ of the score and dP chains, and a negation per query block
-    // and wave is eight VALU instructions in a loop that is bound by vector issue
+    // and wave is eight VALU instructions in a loop that is bound by vector issue.  Every wave holds the same 64 rows and
+    // writes the same words (no `threadIdx.x < 64` branch: a consumer under a branch leaves the loads "pending" on the other
+    // waves' path in hipcc's wait bookkeeping — attn_flash.hip, dK/dV kernel)
     __device__ __forceinline__ void store(float* lse_s, float* delta_s) const {
-        if (threadIdx.x < 64) {
-            lse_s[threadIdx.x] = -lse;
-            delta_s[threadIdx.x] = -delta;
-        }
+        lse_s[threadIdx.x & 63] = ok ? -lse : -INFINITY;
+        delta_s[threadIdx.x & 63] = ok ? -delta : 0.f;
     }
-    // without a branch: every wave holds the same 64 rows and writes the same words
-    __device__ __forceinline__ void store_unmasked(float* lse_s, float* delta_s) const {
-        lse_s[threadIdx.x & 63] = -lse;
-        delta_s[threadIdx.x & 63] = -delta;
-    }
+    __device__ __forceinline__ void store_unmasked(float* lse_s, float* delta_s) const { store(lse_s, delta_s); }
 };
-
 }  // namespace

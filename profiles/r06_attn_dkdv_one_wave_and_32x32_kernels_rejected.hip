@@ -61,7 +61,7 @@ template <typename T> constexpr int narrow_lds_bytes() {
     return kNB * (2 * FlashShape<2, 3>::K_HALFS * (int)sizeof(T) + 2 * 64 * 4) + 256 * 16;  // ring + a 16-byte dump per thread
 }
 
-template <typename T, bool RAGGED_KEYS>
+template <typename T>
 __global__ __launch_bounds__(256, 1) void attn_flash_dkdv_narrow_kernel(const T* __restrict__ Q, const T* __restrict__ K,
                                                                       const T* __restrict__ V, const T* __restrict__ dO,
                                                                       const float* __restrict__ LSE,
@@ -155,9 +155,7 @@ __global__ __launch_bounds__(256, 1) void attn_flash_dkdv_narrow_kernel(const T*
     // loads of the resident V fragments into the loop as "pending" and puts an s_waitcnt vmcnt(0) in front of their first use
     // in EVERY iteration — behind the tile loads, whose latency that wait then exposes on every tile
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    bool key_ok[NKW];
-#pragma unroll
-    for (int nf = 0; nf < NKW; ++nf) key_ok[nf] = key0 + nf * 16 + l15 < Tk;
+    // (keys past Tk need no masking: attn_flash.hip, dK/dV kernel)
 
     // One pair: 32 query rows of ring slot `slot`; (nslot, nr0) = where the NEXT pair's row fragments are.  The instruction
     // ORDER below is the schedule: at one wave per SIMD nothing else fills an issue slot, so every MFMA is followed by the
@@ -211,10 +209,6 @@ __global__ __launch_bounds__(256, 1) void attn_flash_dkdv_narrow_kernel(const T*
                 e[3] = fast_exp2(s2[3]);
             }
             if (i == 2) {
-                if constexpr (RAGGED_KEYS) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) e[r] = key_ok[nf] ? e[r] : 0.f;
-                }
                 pa[nf].w[hb * 2] = pack2<T>(e[0], e[1]);
                 pa[nf].w[hb * 2 + 1] = pack2<T>(e[2], e[3]);
             }
@@ -315,26 +309,237 @@ __global__ __launch_bounds__(256, 1) void attn_flash_dkdv_narrow_kernel(const T*
         }
 }
 
+// =====================================================================================================================
+// 32x32x16 form (round 6, second kernel of this file).  What the issue-cost measurements (tools/micro/issue_cost.hip,
+// profiles/r06_issue_cost_*.log) say about these loops: an MFMA costs a wave ~12 issue cycles whatever its shape, a 16x16x32
+// leaves 4 of its 16 pipe cycles for other instructions and a 32x32x16 leaves 20 of its 32 — and v_exp_f32 (8.6 cycles) plus
+// the multiply / convert per score do not fit under 16x16 MFMAs: the two-wave kernel runs at MFMA time PLUS vector time.
+// Here every product is a 32x32x16:
+//   S′[q, key] = Q·Kᵀ − LSE and dP′ = dO·Vᵀ − Δ with the QUERY rows as the first operand (row fragments straight from the
+//     row-major LDS tile, ds_read_b128) and the wave's keys as the second (8 consecutive head-dim values of a key row: a plain
+//     16-byte global load, resident): 3 K-steps cover 48 head channels — 6 MFMAs per 32x32 scores instead of 16;
+//   the accumulator tile has the key on the lane and 16 query rows in its registers, which IS the first operand of the
+//     contractions over the query rows (cdna_hip_programming.md §3, "an accumulator tile as the next MFMA's operand"):
+//     registers 8t..8t+7, converted pairwise, are K-step t of dV[key, c] += Pᵀ·dO and dK[key, c] += dSᵀ·Q; the second operand
+//     (lane = head channel c, same query rows) comes from the transposing LDS read of the same tiles;
+//   a wave owns 32 keys (dK / dV: 2 x 2 accumulator tiles of 32 keys x 32 channels, 64 registers), a workgroup 128, two
+//     workgroups per CU as before.
+// LDS rows are 144 bytes here (72 halfs): the 32-row first-operand reads are then conflict-free under gfx950's ds_read_b128 lane
+// groups (MI355X_MICROARCH.md, LDS); the transposing reads of a 32-channel block touch 4 rows x 16 dwords per half-wave and
+// collide on 8 of the 64 banks.
+struct Mx32Shape {
+    static constexpr int KROW = 72;
+    static constexpr int IT = 2;  // 64 rows x (d <= 48)/8 chunks over 256 threads
+    static constexpr int K_HALFS = kTile * KROW;
+};
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <typename T> struct Mma32;
+template <> struct Mma32<half_t> {
+    static __device__ __forceinline__ f32x16 run(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mma32<bf16_t> {
+    static __device__ __forceinline__ f32x16 run(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <typename T> constexpr int mx32_lds_bytes() { return 4 * Mx32Shape::K_HALFS * (int)sizeof(T) + 4 * 64 * 4; }
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_flash_dkdv_mx32_kernel(const T* __restrict__ Q, const T* __restrict__ K,
+                                                                    const T* __restrict__ V, const T* __restrict__ dO,
+                                                                    const float* __restrict__ LSE,
+                                                                    const float* __restrict__ Delta, T* __restrict__ dK,
+                                                                    T* __restrict__ dV, int Tq, int Tk, int H, int d,
+                                                                    float scale, float scale_log2e, int64_t ldq,
+                                                                    int64_t ld_dq) {
+    using S = Mx32Shape;
+    using F8 = typename Mma<T>::F8;
+    using Pk4 = PkOperand<T>;
+    constexpr int KT = 3;   // 16-deep K-steps over the head channels (d <= 48)
+    constexpr int CB = 2;   // 32-channel blocks of dK / dV (channels >= d are padding: zero columns of the LDS tiles)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Qs = reinterpret_cast<T*>(smem);          // [2][64][KROW]
+    T* Gs = Qs + 2 * S::K_HALFS;                  // [2][64][KROW]
+    float* lse_s = reinterpret_cast<float*>(Gs + 2 * S::K_HALFS);  // [2][64]  (−LSE)
+    float* delta_s = lse_s + 2 * 64;                               // [2][64]  (−Δ)
+
+    int bx, bh;
+    xcd_block(bx, bh);
+    const int b = bh / H, h = bh - b * H;
+    const int64_t HD = (int64_t)H * d;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c32 = lane & 31, hh = lane >> 5;
+    const T* Qh = Q + (int64_t)b * Tq * ldq + h * d;
+    const T* Gh = dO + (int64_t)b * Tq * HD + h * d;
+    const T* Kh = K + (int64_t)b * Tk * ldq + h * d;
+    const T* Vh = V + (int64_t)b * Tk * ldq + h * d;
+    const float* lse_h = LSE + (int64_t)bh * Tq;
+    const float* delta_h = Delta + (int64_t)bh * Tq;
+    const int key0 = bx * 128 + wave * 32;  // first key of this wave
+    const bool key_ok = key0 + c32 < Tk;  // (loads only: keys past Tk need no masking — attn_flash.hip, dK/dV kernel)
+
+    // the wave's keys as SECOND operands of the score products: lane = key c32, K-step s holds head channels 16s + 8·hh + 0..7
+    F8 kB[KT], vB[KT];
+    {
+        const int key = key0 + c32;
+#pragma unroll
+        for (int s = 0; s < KT; ++s) {
+            const int col = 16 * s + 8 * hh;
+            const bool ok = key_ok && col < d;
+            const Chunk<T> kc = load_or_zero<T>(ok ? Kh + (int64_t)key * ldq + col : Kh, ok);
+            const Chunk<T> vc = load_or_zero<T>(ok ? Vh + (int64_t)key * ldq + col : Vh, ok);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                kB[s][e] = from_f32<T>(to_f32<T>(kc.v[e]) * scale_log2e);  // scores leave the matrix pipe in the exp2 domain
+                vB[s][e] = vc.v[e];
+            }
+        }
+    }
+    f32x16 dk[CB], dv[CB];  // D[key, c]: lane = channel 32·cb + c32, register r = key (r&3) + 8(r>>2) + 4·hh of the wave's 32
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dk[cb][r] = dv[cb][r] = 0.f;
+
+    lds_zero(smem, mx32_lds_bytes<T>());
+    __syncthreads();
+    TileStageS<T, S> stage;
+    RowStats stats;
+    stage.init(d, ldq, HD);
+    stage.load(Qh, Gh, Tq);
+    stats.load(lse_h, delta_h, 0, Tq);
+    stage.store_a_rows(Qs);
+    stage.store_b_rows(Gs);
+    stats.store(lse_s, delta_s);
+    __syncthreads();
+    const int n_tiles = (Tq + 63) / 64;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): no prologue load is carried into the loop as "pending" (attn_flash.hip)
+
+    // transposing-read address of this lane inside a tile: 16-lane group gi reads 4 rows x 16 channels — rows 4·(gi>>1) + (i>>2)
+    // of the block, channels 16·(gi&1) + 4·(i&3) of the 32-channel block (lane i of the group receives channel i of the rows)
+    const int tr_lane_off = (4 * (lane >> 5) + ((lane & 15) >> 2)) * S::KROW + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
+    for (int qt = 0; qt < n_tiles; ++qt) {
+        const int cur = qt & 1;
+        const T* Qc = Qs + cur * S::K_HALFS;
+        const T* Gc = Gs + cur * S::K_HALFS;
+        const float* lc = lse_s + cur * 64;
+        const float* dc = delta_s + cur * 64;
+        if (qt + 1 < n_tiles) {
+            stage.load(Qh + (int64_t)(qt + 1) * 64 * ldq, Gh + (int64_t)(qt + 1) * 64 * HD, Tq - (qt + 1) * 64);
+            stats.load(lse_h, delta_h, (qt + 1) * 64, Tq);
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {  // 32 query rows at a time
+            const int r0 = qb * 32;
+            // row fragments (first operand: lane = query row r0 + c32, channels 16s + 8·hh + 0..7) and the row constants in the
+            // accumulators' own layout (register 4g + i = row r0 + 8g + 4·hh + i)
+            F8 qA[KT], gA[KT];
+#pragma unroll
+            for (int s = 0; s < KT; ++s) {
+                const int off = (r0 + c32) * S::KROW + 16 * s + 8 * hh;
+                qA[s] = *reinterpret_cast<const F8*>(Qc + off);
+                gA[s] = *reinterpret_cast<const F8*>(Gc + off);
+            }
+            f32x16 sc, dp;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lc + r0 + 8 * g + 4 * hh);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dc + r0 + 8 * g + 4 * hh);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    sc[4 * g + i] = l4[i];
+                    dp[4 * g + i] = d4[i];
+                }
+            }
+            // (two batches of LDS reads per block, pinned: hipcc otherwise issues each read right in front of its MFMA — ten exposed
+            //  LDS round trips per block with only two waves per SIMD to cover them.  The first batch feeds the score products;
+            //  the second — the transposed second operands of dV / dK: K-step t = rows r0 + 16t + {0, 8} + 4·hh + 0..3 — is
+            //  issued before those products start and lands under them and the exponents)
+            __builtin_amdgcn_sched_barrier(0);
+            F8 gT[2][CB], qT[2][CB];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    const int base = (r0 + 16 * t) * S::KROW + 32 * cb + tr_lane_off;
+                    gT[t][cb] = tr_pair<T>(lds_tr_at(Gc + base), lds_tr_at(Gc + base + 8 * S::KROW));
+                    qT[t][cb] = tr_pair<T>(lds_tr_at(Qc + base), lds_tr_at(Qc + base + 8 * S::KROW));
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < KT; ++s) {
+                sc = Mma32<T>::run(qA[s], kB[s], sc);
+                dp = Mma32<T>::run(gA[s], vB[s], dp);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // p = exp2(s′), dS = p·dP′ (1/√d goes onto dK at the end); registers 8t..8t+7 → K-step t of the next products
+            Pk4 pa[2], dsa[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const float p0 = fast_exp2(sc[8 * t + 2 * w]), p1 = fast_exp2(sc[8 * t + 2 * w + 1]);
+                    pa[t].w[w] = pack2<T>(p0, p1);
+                    dsa[t].w[w] = pack2<T>(p0 * dp[8 * t + 2 * w], p1 * dp[8 * t + 2 * w + 1]);
+                }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    dv[cb] = Mma32<T>::run(pa[t].f8(), gT[t][cb], dv[cb]);
+                    dk[cb] = Mma32<T>::run(dsa[t].f8(), qT[t][cb], dk[cb]);
+                }
+        }
+        if (qt + 1 < n_tiles) {
+            stage.store_a_rows(Qs + (cur ^ 1) * S::K_HALFS);
+            stage.store_b_rows(Gs + (cur ^ 1) * S::K_HALFS);
+            stats.store(lse_s + (cur ^ 1) * 64, delta_s + (cur ^ 1) * 64);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        const int c = 32 * cb + c32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (key < Tk && c < d) {
+                const int64_t off = ((int64_t)b * Tk + key) * ld_dq + h * d + c;
+                dK[off] = from_f32<T>(dk[cb][r] * scale);
+                dV[off] = from_f32<T>(dv[cb][r]);
+            }
+        }
+    }
+}
+
+template <typename T> int launch_dkdv_mx32(const LoraFlashBwdArgs& a, hipStream_t stream) {
+    constexpr int lds = mx32_lds_bytes<T>();
+    auto k0 = attn_flash_dkdv_mx32_kernel<T>;
+    const dim3 grid((unsigned)((a.Tk + 127) / 128), (unsigned)(a.B * a.H));
+    {
+        const double bh = (double)a.B * a.H, e = sizeof(T);
+        lora_prof_set_work(e * bh * a.d * (2.0 * a.Tq + 4.0 * a.Tk), 6.0 * bh * a.Tq * (double)a.Tk * a.d);
+    }
+    const float l2e = a.scale * 1.4426950408889634f;
+    LORA_LAUNCH(PK_FLASH_DKDV, k0, grid, dim3(256), lds, stream, static_cast<const T*>(a.Q), static_cast<const T*>(a.K),
+                    static_cast<const T*>(a.V), static_cast<const T*>(a.dO), a.LSE, a.delta, static_cast<T*>(a.dK),
+                    static_cast<T*>(a.dV), a.Tq, a.Tk, a.H, a.d, a.scale, l2e, a.ldq, a.ld_dq);
+    lora_prof_set_work(0.0, 0.0);
+    LORA_LAUNCH_CHECK();
+    return LORA_OK;
+}
+
 template <typename T> int launch_dkdv_narrow(const LoraFlashBwdArgs& a, hipStream_t stream) {
     constexpr int lds = narrow_lds_bytes<T>();
-    const bool ragged = (a.Tk % 64) != 0;  // some wave of the last workgroup owns keys past the end
-    auto k0 = attn_flash_dkdv_narrow_kernel<T, false>;
-    auto k1 = attn_flash_dkdv_narrow_kernel<T, true>;
+    auto k0 = attn_flash_dkdv_narrow_kernel<T>;
     static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (attr0 != hipSuccess || attr1 != hipSuccess) return LORA_E_LAUNCH;
+    if (attr0 != hipSuccess) return LORA_E_LAUNCH;
     const dim3 grid((unsigned)((a.Tk + 255) / 256), (unsigned)(a.B * a.H));
     {
         const double bh = (double)a.B * a.H, e = sizeof(T);
         lora_prof_set_work(e * bh * a.d * (2.0 * a.Tq + 4.0 * a.Tk), 6.0 * bh * a.Tq * (double)a.Tk * a.d);
     }
     const float l2e = a.scale * 1.4426950408889634f;
-    if (ragged)
-        LORA_LAUNCH(PK_FLASH_DKDV, k1, grid, dim3(256), lds, stream, static_cast<const T*>(a.Q), static_cast<const T*>(a.K),
-                    static_cast<const T*>(a.V), static_cast<const T*>(a.dO), a.LSE, a.delta, static_cast<T*>(a.dK),
-                    static_cast<T*>(a.dV), a.Tq, a.Tk, a.H, a.d, a.scale, l2e, a.ldq, a.ld_dq);
-    else
-        LORA_LAUNCH(PK_FLASH_DKDV, k0, grid, dim3(256), lds, stream, static_cast<const T*>(a.Q), static_cast<const T*>(a.K),
+    LORA_LAUNCH(PK_FLASH_DKDV, k0, grid, dim3(256), lds, stream, static_cast<const T*>(a.Q), static_cast<const T*>(a.K),
                     static_cast<const T*>(a.V), static_cast<const T*>(a.dO), a.LSE, a.delta, static_cast<T*>(a.dK),
                     static_cast<T*>(a.dV), a.Tq, a.Tk, a.H, a.d, a.scale, l2e, a.ldq, a.ld_dq);
     lora_prof_set_work(0.0, 0.0);
@@ -350,9 +555,16 @@ extern "C" int lora_flash_read_stamps(unsigned long long* host64) {
 }
 #endif
 
-int lora_flash_dkdv_narrow(const LoraFlashBwdArgs& a, int dtype, hipStream_t stream) {
+int lora_flash_dkdv_narrow(const LoraFlashBwdArgs& a, int dtype, hipStream_t stream, int form) {
     if (a.d > 48 || a.d < 8 || (a.d % 8) != 0) return LORA_E_BADARG;
-    switch (dtype) {
+    if (form == 2) {  // 32x32x16 products, two workgroups per CU
+        switch (dtype) {
+            case LORA_F16: return launch_dkdv_mx32<half_t>(a, stream);
+            case LORA_BF16: return launch_dkdv_mx32<bf16_t>(a, stream);
+            default: return LORA_E_BADARG;
+        }
+    }
+    switch (dtype) {  // one wave per SIMD, 16x16x32 products
         case LORA_F16: return launch_dkdv_narrow<half_t>(a, stream);
         case LORA_BF16: return launch_dkdv_narrow<bf16_t>(a, stream);
         default: return LORA_E_BADARG;
