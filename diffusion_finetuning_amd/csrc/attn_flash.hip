@@ -457,13 +457,14 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
 
     lds_zero(smem, flash_dkdv_lds_bytes<KS, DF>());
     __syncthreads();
-    TileStage<T, KS, DF> stage;
+    TileStageS<T, S> stage;  // (raw 128-bit chunks + settle(): attn_flash_common.h)
     RowStats stats;
     stage.init(d, ldq, HD);
     stage.load(Qh, Gh, Tq);
     stats.load(lse_h, delta_h, 0, Tq);
     stage.store_a_rows(Qs);
     stage.store_b_rows(Gs);
+    stage.settle();
     stats.store(lse_s, delta_s);
     __syncthreads();
     const int n_tiles = (Tq + 63) / 64;
@@ -578,6 +579,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkdv_kernel(const T* __rest
         if (qt + 1 < n_tiles) {
             stage.store_a_rows(Qs + (cur ^ 1) * S::K_HALFS);
             stage.store_b_rows(Gs + (cur ^ 1) * S::K_HALFS);
+            stage.settle();
             stats.store(lse_s + (cur ^ 1) * 64, delta_s + (cur ^ 1) * 64);
         }
         __syncthreads();

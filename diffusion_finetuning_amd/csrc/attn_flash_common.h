@@ -53,85 +53,147 @@ __device__ __forceinline__ u32x4 load16_or_zero(const void* p, bool ok) {
     return ok ? v : u32x4{0u, 0u, 0u, 0u};
 }
 
-template <typename T, typename S> struct TileStageS {  // S: a shape with KROW (halfs per LDS row) and IT (16-byte chunks per thread)
+template <typename T, typename S> struct TileStageS {
     // (raw 128-bit registers, not element arrays: with 16-bit ELEMENTS on the ragged path hipcc merges the two paths of
     // load() element-wise and re-packs every chunk with v_alignbit / v_perm right behind its load — an s_waitcnt vmcnt
     // that exposes the whole load latency on every tile)
     u32x4 a[S::IT], b[S::IT];
-    // ONE register of map per chunk — row | column << 8, row 255 = the thread has no such chunk — and the two row strides: the
-    // offsets are two multiply-adds per chunk and tile.  (Round 5 kept row, LDS offset, 64-bit source offset and a flag per
-    // chunk: 5 registers each; the kernels that use this sit at the 256-register limit of two waves per SIMD, and a spilled
-    // address comes back through a scratch load — which counts in vmcnt: the wait for it also waits for the tile loads just
-    // issued.)  64·lda fits 31 bits (checked by the entry points), so the in-tile source offset is an int.
-    int rc[S::IT];
-    int lda_, ldb_;
+    int64_t src[S::IT];           // element offset of the chunk inside tile 0 of A
+    int dld;                      // row stride of B minus row stride of A (uniform): B's offset = src + row·dld
+    int row[S::IT], rowoff[S::IT];  // row; offset in a row-major [64][KROW] tile
+    bool have[S::IT];
+    // (round 6 also tried ONE packed register of map per chunk, offsets recomputed per tile: the dQ kernel gained 2 %, the
+    //  4096-token dK/dV launch lost 6 % — profiles/r06_flash_dkdv_stage_state_bisect.log — and kept this form)
 #ifdef FLASH_ABL_NOSTAGE
     bool staged_once = false;
 #endif
-    __device__ __forceinline__ bool have(int i) const { return (rc[i] & 255) != 255; }
-    __device__ __forceinline__ int row(int i) const { return rc[i] & 255; }
-    __device__ __forceinline__ int col(int i) const { return rc[i] >> 8; }
     __device__ __forceinline__ void init(int d, int64_t lda, int64_t ldb) {
         const int cpr = d >> 3, n = kTile * cpr;
-        lda_ = (int)lda;
-        ldb_ = (int)ldb;
+        dld = (int)(ldb - lda);
 #pragma unroll
         for (int i = 0; i < S::IT; ++i) {
             const int idx = threadIdx.x + i * 256;
-            const int r = idx / cpr, c = (idx - r * cpr) * 8;
-            rc[i] = idx < n ? (r | (c << 8)) : 255;
+            have[i] = idx < n;
+            const int r = have[i] ? idx / cpr : 0, c = have[i] ? (idx - r * cpr) * 8 : 0;
+            row[i] = r;
+            src[i] = (int64_t)r * lda + c;
+            rowoff[i] = r * S::KROW + c;
         }
     }
-    // A, B: first row of the tile in each tensor; rows_valid >= 64 for a full tile.
-    // Every load issued before this call must have been consumed (it is: a tile's chunks go to LDS before the barrier that ends
-    // the tile).  The explicit wait states that to hipcc: the chunks are stored under `have(i)`, so on the other lanes' path its
-    // wait bookkeeping still counts the previous tile's loads as pending, and depending on the register allocation it then puts
-    // an s_waitcnt vmcnt(0) BETWEEN this tile's loads or behind them (round 6: +30 µs on the 4096-token dK/dV launch when a
-    // one-line change elsewhere moved two address registers) — nothing is in flight here, so this wait costs nothing.
+    // A, B: first row of the tile in each tensor; rows_valid >= 64 for a full tile
     __device__ __forceinline__ void load(const T* A, const T* B, int rows_valid) {
 #ifdef FLASH_ABL_NOSTAGE  // diagnostic builds only (timing; results are wrong): every tile after the first re-uses tile 0's rows
         if (staged_once) return;
         staged_once = true;
 #endif
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         if (rows_valid >= kTile) {
 #pragma unroll
             for (int i = 0; i < S::IT; ++i) {
-                const int r = have(i) ? row(i) : 0, c = have(i) ? col(i) : 0;
-                a[i] = *reinterpret_cast<const u32x4*>(A + (r * lda_ + c));
-                b[i] = *reinterpret_cast<const u32x4*>(B + (r * ldb_ + c));
+                const int64_t off = have[i] ? src[i] : 0;
+                int rr = have[i] ? row[i] : 0;
+                asm volatile("" : "+v"(rr));  // recompute rr·dld at every tile: hoisted out of the loop it costs registers
+                a[i] = *reinterpret_cast<const u32x4*>(A + off);
+                b[i] = *reinterpret_cast<const u32x4*>(B + off + rr * dld);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < S::IT; ++i) {
-                const bool ok = have(i) && row(i) < rows_valid;
-                const int r = ok ? row(i) : 0, c = ok ? col(i) : 0;
-                a[i] = load16_or_zero(A + (r * lda_ + c), ok);
-                b[i] = load16_or_zero(B + (r * ldb_ + c), ok);
+                const bool ok = have[i] && row[i] < rows_valid;
+                const int64_t off = ok ? src[i] : 0;
+                int rr = ok ? row[i] : 0;
+                asm volatile("" : "+v"(rr));
+                a[i] = load16_or_zero(A + off, ok);
+                b[i] = load16_or_zero(B + off + rr * dld, ok);
+            }
+        }
+    }
+    // Call after the chunks of a tile have gone to LDS (store_*_rows).  The chunks are stored under `have[i]`, so on the other
+    // lanes' path hipcc's wait bookkeeping still counts the tile's loads as pending, carries that into the next iteration and —
+    // depending on the register allocation — puts an s_waitcnt vmcnt(0) BETWEEN the next tile's loads or right behind them,
+    // which exposes their whole latency on every tile (round 6: +30 µs on the 4096-token dK/dV launch after a one-line change
+    // elsewhere moved two address registers).  Here the loads are a tile old: the wait is free, and it settles the bookkeeping.
+    // (In FRONT of the next tile's loads the same wait cost 2.5 % of that launch: it pins the order of everything around it.)
+    __device__ __forceinline__ void settle() const { __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0)
+    __device__ __forceinline__ void store_a_rows(T* dst) const {
+#pragma unroll
+        for (int i = 0; i < S::IT; ++i)
+            if (have[i]) *reinterpret_cast<u32x4*>(dst + rowoff[i]) = a[i];
+    }
+    __device__ __forceinline__ void store_b_rows(T* dst) const {
+#pragma unroll
+        for (int i = 0; i < S::IT; ++i)
+            if (have[i]) *reinterpret_cast<u32x4*>(dst + rowoff[i]) = b[i];
+    }
+    // both tiles without a branch: a thread's chunks beyond the tile go to `dump` (16 bytes of LDS of its own)
+    __device__ __forceinline__ void store_rows_unmasked(T* dst_a, T* dst_b, T* dump) const {
+#pragma unroll
+        for (int i = 0; i < S::IT; ++i) {
+            *reinterpret_cast<u32x4*>(have[i] ? dst_a + rowoff[i] : dump) = a[i];
+            *reinterpret_cast<u32x4*>(have[i] ? dst_b + rowoff[i] : dump) = b[i];
+        }
+    }
+};
+
+// The forward and dQ kernels keep round 5's form of the stage (16-bit element chunks): they never had a wait behind their tile
+// loads, and with the raw-register form above the dQ kernel measured 3 % slower on one box (profiles/r06_flash_final_ab.log).
+// One 64-row tile of two [rows, H·d] tensors (K and V, or Q and dO) on its way global → registers → LDS.
+// The chunk map is fixed for the whole kernel and computed once: a thread owns up to IT 16-byte chunks (row, col) of
+// the d/8 REAL chunks of each row — the padding columns of the LDS tiles are zeroed once, never re-staged — so a full
+// tile costs one 64-bit add and two unpredicated loads per chunk, no selects; only a ragged last tile checks rows.
+template <typename T, int KS, int DF> struct TileStage {
+    using S = FlashShape<KS, DF>;
+    Chunk<T> a[S::IT], b[S::IT];
+    int64_t src[S::IT];           // element offset of the chunk inside tile 0 of A
+    int dld;                      // row stride of B minus row stride of A (uniform): B's offset = src + row·dld
+    int row[S::IT], rowoff[S::IT];  // row; offset in a row-major [64][KROW] tile
+    bool have[S::IT];
+    __device__ __forceinline__ void init(int d, int64_t lda, int64_t ldb) {
+        const int cpr = d >> 3, n = kTile * cpr;
+        dld = (int)(ldb - lda);
+#pragma unroll
+        for (int i = 0; i < S::IT; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            have[i] = idx < n;
+            const int r = have[i] ? idx / cpr : 0, c = have[i] ? (idx - r * cpr) * 8 : 0;
+            row[i] = r;
+            src[i] = (int64_t)r * lda + c;
+            rowoff[i] = r * S::KROW + c;
+        }
+    }
+    // A, B: first row of the tile in each tensor; rows_valid >= 64 for a full tile
+    __device__ __forceinline__ void load(const T* A, const T* B, int rows_valid) {
+        if (rows_valid >= kTile) {
+#pragma unroll
+            for (int i = 0; i < S::IT; ++i) {
+                const int64_t off = have[i] ? src[i] : 0;
+                int rr = have[i] ? row[i] : 0;
+                asm volatile("" : "+v"(rr));  // recompute rr·dld at every tile: hoisted out of the loop it costs registers
+                a[i] = *reinterpret_cast<const Chunk<T>*>(A + off);
+                b[i] = *reinterpret_cast<const Chunk<T>*>(B + off + rr * dld);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < S::IT; ++i) {
+                const bool ok = have[i] && row[i] < rows_valid;
+                const int64_t off = ok ? src[i] : 0;
+                int rr = ok ? row[i] : 0;
+                asm volatile("" : "+v"(rr));
+                a[i] = load_or_zero<T>(A + off, ok);
+                b[i] = load_or_zero<T>(B + off + rr * dld, ok);
             }
         }
     }
     __device__ __forceinline__ void store_a_rows(T* dst) const {
 #pragma unroll
         for (int i = 0; i < S::IT; ++i)
-            if (have(i)) *reinterpret_cast<u32x4*>(dst + row(i) * S::KROW + col(i)) = a[i];
+            if (have[i]) *reinterpret_cast<Chunk<T>*>(dst + rowoff[i]) = a[i];
     }
     __device__ __forceinline__ void store_b_rows(T* dst) const {
 #pragma unroll
         for (int i = 0; i < S::IT; ++i)
-            if (have(i)) *reinterpret_cast<u32x4*>(dst + row(i) * S::KROW + col(i)) = b[i];
-    }
-    // both tiles without a branch: a thread's chunks beyond the tile go to `dump` (16 bytes of LDS of its own)
-    __device__ __forceinline__ void store_rows_unmasked(T* dst_a, T* dst_b, T* dump) const {
-#pragma unroll
-        for (int i = 0; i < S::IT; ++i) {
-            const int off = row(i) * S::KROW + col(i);
-            *reinterpret_cast<u32x4*>(have(i) ? dst_a + off : dump) = a[i];
-            *reinterpret_cast<u32x4*>(have(i) ? dst_b + off : dump) = b[i];
-        }
+            if (have[i]) *reinterpret_cast<Chunk<T>*>(dst + rowoff[i]) = b[i];
     }
 };
-template <typename T, int KS, int DF> using TileStage = TileStageS<T, FlashShape<KS, DF>>;
 
 
 // zero `bytes` of LDS (multiple of 16) cooperatively: the padding columns / rows of the tiles stay zero for the kernel's life
@@ -221,4 +283,5 @@ struct RowStats {
     }
     __device__ __forceinline__ void store_unmasked(float* lse_s, float* delta_s) const { store(lse_s, delta_s); }
 };
+
 }  // namespace
