@@ -349,7 +349,11 @@ def lora_grad_batched(problems, dtype: torch.dtype, device) -> None:
     n = len(problems)
     if n == 0:
         return
-    arr = (GradProblem * n)(*problems)
+    lora_grad_batched_array((GradProblem * n)(*problems), n, dtype, device)
+
+
+def lora_grad_batched_array(arr, n: int, dtype: torch.dtype, device) -> None:
+    """The same on a `(GradProblem * n)` array the caller keeps (ops._SinkPlan re-uses one from step to step)."""
     stream = _raw_stream(device.index) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream
     _check(lib().lora_grad_batched(arr, n, dtype_code(dtype), stream), "lora_grad_batched")
 
@@ -700,10 +704,16 @@ def attn_merge_heads(x4, d: int):
     return out
 
 
+_attn_supported = {}  # (core, shape, dtype) → bool: a pure function of the library, asked 2–3 times per attention call
+
+
 def attn_ctx_supported(B: int, Tq: int, Tk: int, H: int, d: int, dtype) -> bool:
-    if dtype not in (torch.float16, torch.bfloat16):
-        return False
-    return bool(lib().attn_ctx_supported(B, Tq, Tk, H, d, dtype_code(dtype)))
+    key = (0, B, Tq, Tk, H, d, dtype)
+    ok = _attn_supported.get(key)
+    if ok is None:
+        ok = _attn_supported[key] = (dtype in (torch.float16, torch.bfloat16) and
+                                     bool(lib().attn_ctx_supported(B, Tq, Tk, H, d, dtype_code(dtype))))
+    return ok
 
 
 def attn_ctx_fwd(q, k, v, heads: int, scale: float):
@@ -799,9 +809,12 @@ def attn_flash_bwd_qkv(qkv, out, dout, lse, heads: int, scale: float):
 
 
 def attn_flash_supported(B: int, Tq: int, Tk: int, H: int, d: int, dtype) -> bool:
-    if dtype not in (torch.float16, torch.bfloat16):
-        return False
-    return bool(lib().attn_flash_supported(B, Tq, Tk, H, d, dtype_code(dtype)))
+    key = (1, B, Tq, Tk, H, d, dtype)
+    ok = _attn_supported.get(key)
+    if ok is None:
+        ok = _attn_supported[key] = (dtype in (torch.float16, torch.bfloat16) and
+                                     bool(lib().attn_flash_supported(B, Tq, Tk, H, d, dtype_code(dtype))))
+    return ok
 
 
 def attn_flash_fwd(q, k, v, heads: int, scale: float, want_lse: bool = True):

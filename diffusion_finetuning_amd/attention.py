@@ -20,6 +20,9 @@ import torch
 from torch import nn
 
 from . import _native as nat
+from ._fastattr import factor_weights, linear_params
+from .groups import ctx_cross_attention, qkv_self_attention
+from .ops import feed_forward_geglu
 from .sandwich import ctx_attention, flash_attention
 
 ATTENTION_CLASS_NAMES = {"CrossAttention", "Attention"}
@@ -62,10 +65,11 @@ def _hip_forward(self, hidden_states, *args, **kwargs):
         ctx = hidden_states
     core = None
     cdtype = _compute_dtype(hidden_states)
+    to_q = self.to_q
+    width = _out_features(to_q)
     if (not unknown and mask is None and hidden_states.is_cuda and hidden_states.dim() == 3 and ctx.dim() == 3
-            and _out_features(self.to_q) % heads == 0):
-        shape = (hidden_states.shape[0], hidden_states.shape[1], ctx.shape[1], heads, _out_features(self.to_q) // heads,
-                 cdtype)
+            and width % heads == 0):
+        shape = (hidden_states.shape[0], hidden_states.shape[1], ctx.shape[1], heads, width // heads, cdtype)
         if nat.attn_ctx_supported(*shape):      # up to 128 keys: the whole K/V of a head in LDS, one tile
             core = ctx_attention
         elif nat.attn_flash_supported(*shape):  # any length: online softmax over key tiles
@@ -80,15 +84,11 @@ def _hip_forward(self, hidden_states, *args, **kwargs):
     qkv = self.__dict__.get("_dfa_qkv")
     kvg = self.__dict__.get("_dfa_ctx")
     if self_attention and qkv is not None and qkv.usable(hidden_states, cdtype) and nat.attn_flash_supported(*shape):
-        from .groups import qkv_self_attention
-
         out = qkv_self_attention(qkv, hidden_states, heads, scale, cdtype)
     elif not self_attention and kvg is not None and core is ctx_attention and kvg[0].usable(ctx, cdtype):
-        from .groups import ctx_cross_attention
-
-        out = ctx_cross_attention(kvg[0], kvg[1], self.to_q(hidden_states), ctx, heads, scale, cdtype)
+        out = ctx_cross_attention(kvg[0], kvg[1], to_q(hidden_states), ctx, heads, scale, cdtype)
     else:
-        q, k, v = self.to_q(hidden_states), self.to_k(ctx), self.to_v(ctx)
+        q, k, v = to_q(hidden_states), self.to_k(ctx), self.to_v(ctx)
         if q.dtype != k.dtype:  # mixed module dtypes outside autocast: compute in the query's dtype
             k, v = k.to(q.dtype), v.to(q.dtype)
         out = core(q, k, v, heads, scale)
@@ -220,17 +220,17 @@ def _hip_feed_forward(self, hidden_states, *args, **kwargs):
     `proj` LoRA launch, backward in the launch that computes the second linear layer's input gradient.  Anything outside
     that envelope — extra arguments, active dropout, a `proj` that is not a plain LoraInjectedLinear, a second layer that is
     trainable or hooked, no gradient wanted — takes the module's own forward (whose GEGLU keeps its forward-only fusion)."""
-    geglu, drop, lin2 = self.net[0], self.net[1], self.net[2]
+    geglu, drop, lin2 = self.net  # (a ModuleList of three: _is_geglu_feed_forward)
+    proj = geglu.proj
+    w2, b2 = linear_params(lin2)
     ok = (not args and not kwargs and hidden_states.is_cuda and torch.is_grad_enabled()
-          and not (drop.training and drop.p > 0) and _plain_lora_linear(geglu.proj)
+          and not (drop.training and drop.p > 0) and _plain_lora_linear(proj)
           and "forward" not in lin2.__dict__ and not lin2._forward_hooks and not lin2._forward_pre_hooks
-          and not lin2.weight.requires_grad and (lin2.bias is None or not lin2.bias.requires_grad)
-          and (hidden_states.requires_grad or geglu.proj.lora_up.weight.requires_grad))
+          and not w2.requires_grad and (b2 is None or not b2.requires_grad)
+          and (hidden_states.requires_grad or factor_weights(proj)[1].requires_grad))
     if not ok:
         return self.__dict__[_ORIG](hidden_states, *args, **kwargs)
-    from .ops import feed_forward_geglu
-
-    return feed_forward_geglu(geglu.proj, lin2, hidden_states)
+    return feed_forward_geglu(proj, lin2, hidden_states)
 
 
 def set_use_hip_geglu(module: nn.Module, valid: bool = True) -> int:

@@ -20,6 +20,7 @@ import torch
 from torch.autograd.function import once_differentiable
 
 from . import _native as nat
+from ._fastattr import factor_weights, frozen_linear
 
 RANK_PAD = 16  # rank slots of one packed factor (kRP in csrc/lora_gemm.hip)
 
@@ -43,7 +44,7 @@ class _FrozenCat:
         self._w = self._wt = None
 
     def get(self, cdtype: torch.dtype, need_wt: bool):
-        ws = [l.linear.weight for l in self.layers]
+        ws = [frozen_linear(l)[0] for l in self.layers]
         key = tuple((w.data_ptr(), w._version, w.dtype, w.device) for w in ws) + (cdtype,)
         if key != self._key:
             self._key, self._w, self._wt = key, _cast_cat(ws, cdtype, False), None
@@ -53,7 +54,7 @@ class _FrozenCat:
 
     def bias(self, cdtype: torch.dtype):
         """[b0; b1; ...] in the compute dtype (None when the members have no bias), rebuilt when a member's bias changes."""
-        bs = [l.linear.bias for l in self.layers]
+        bs = [frozen_linear(l)[1] for l in self.layers]
         if bs[0] is None:
             return None
         key = tuple((b.data_ptr(), b._version, b.dtype, b.device) for b in bs) + (cdtype,)
@@ -155,26 +156,34 @@ class _GradTargets:
         else:
             from .ops import _auto_sink_for
 
-            lay = g.layers[members[0]]
-            sink = _auto_sink_for(lay.lora_down.weight, lay.lora_up.weight)
-            targets = [((g.layers[i].lora_up.weight if up else g.layers[i].lora_down.weight), torch.float32) for i in members]
+            sink = _auto_sink_for(*factor_weights(g.layers[members[0]]))
+            targets = [(factor_weights(g.layers[i])[1 if up else 0], torch.float32) for i in members]
             sink.defer_problem(S, s_off, s_stride, C, P, p_off, p_stride, r, not up, M, scale, targets)
 
 
 def _dropin_ready(group, cdtype) -> bool:
     """A group without a slab: its packed operands come from the members' ops.PackRegistry (refreshed here when a factor
     changed) and its gradients go to the drop-in sink — which must exist for every member (no process group, no hooks)."""
-    from .ops import _auto_sink_for
+    from .ops import deferral_open, param_defers
 
     reg = group.registry
-    if reg is None:
+    if reg is None or not deferral_open():
         return False
     for l in group.layers:
         if "_dfa_grad_sink" in l.__dict__:
             return False  # the member joined a trainer's slab since: its gradients belong there (the slab's own groups, if any)
-        if _auto_sink_for(l.lora_down.weight, l.lora_up.weight) is None:
+        down, up = factor_weights(l)
+        if not (param_defers(down) and param_defers(up)):
             return False
     return reg.ensure(group.layers, cdtype)
+
+
+def _members_frozen(layers) -> bool:
+    """No member's frozen weight asks for a gradient (the grouped launches produce none)."""
+    for l in layers:
+        if frozen_linear(l)[0].requires_grad:
+            return False
+    return True
 
 
 class QKVGroup:
@@ -223,7 +232,7 @@ class QKVGroup:
         if self.sinks is None and not (x.is_cuda and _dropin_ready(self, cdtype)):
             return False
         return (self.Fa is not None and self.Fa.dtype == cdtype and x.is_cuda and _same_scale(self.layers) is not None
-                and all(not l.linear.weight.requires_grad for l in self.layers))
+                and _members_frozen(self.layers))
 
 
 class _QKVProjFn(torch.autograd.Function):
@@ -354,7 +363,7 @@ def shared_projection(group: QKVGroup, member: int, x: torch.Tensor, cdtype: tor
     memo = group.__dict__.get("_memo")
     key = (id(x), x._version, torch.is_grad_enabled())
     if memo is None or memo[0] != key:
-        factors = [p for l in group.layers for p in (l.lora_down.weight, l.lora_up.weight)]
+        factors = [p for l in group.layers for p in factor_weights(l)]
         parts = _SplitQKVFn.apply(_QKVProjFn.apply(x, group, cdtype, *factors), group.N)
         memo = group.__dict__["_memo"] = [key, x, list(parts), 0]  # (x itself is kept: its id cannot be reused meanwhile)
     out = memo[2][member]
@@ -366,7 +375,7 @@ def shared_projection(group: QKVGroup, member: int, x: torch.Tensor, cdtype: tor
 
 def qkv_self_attention(group: QKVGroup, x: torch.Tensor, heads: int, scale: Optional[float], cdtype: torch.dtype):
     """softmax(q kᵀ·scale) v for q, k, v = the group's three LoRA projections of x → [B, T, H·d]."""
-    factors = [p for l in group.layers for p in (l.lora_down.weight, l.lora_up.weight)]
+    factors = [p for l in group.layers for p in factor_weights(l)]
     qkv = _QKVProjFn.apply(x, group, cdtype, *factors)
     if scale is None:
         scale = (group.N // heads) ** -0.5
@@ -441,14 +450,18 @@ class CtxKVGroup:
         # (per-module path); the reentrant form's no-grad forward and every ordinary pass use the group.
         if _in_backward() or _saved_tensor_hooks_active():
             return False
-        # (drop-in mode: the members' packed operands are checked once per pass — by the cross-attention that projects)
-        if self.sinks is None and self._pass is None and not (ctx_t.is_cuda and _dropin_ready(self, cdtype)):
-            return False
+        # The members (32 layers in an SD UNet) are checked once per pass — by the cross-attention that opens it, whose
+        # projection launch serves all of them: packed operands current and gradients deferrable (drop-in mode), one LoRA
+        # scale, frozen weights.  The other 15 consumers of the pass only check what is their own.
+        if self._pass is None:
+            if self.sinks is None and not (ctx_t.is_cuda and _dropin_ready(self, cdtype)):
+                return False
+            if _same_scale(self.layers) is None or not _members_frozen(self.layers):
+                return False
         # (a context that carries a gradient — a text encoder that trains, train_lora_dreambooth.py:608-621, or whose token
         #  embeddings do, cli_lora_pti.py:706-722 — gets its dX from ONE grouped launch as well: _CtxProjFn.backward)
         return (self.A16 is not None and self.A16.dtype == cdtype and ctx_t.is_cuda and ctx_t.dim() == 3 and
-                ctx_t.shape[-1] == self.K and _same_scale(self.layers) is not None and
-                all(not l.linear.weight.requires_grad for l in self.layers))
+                ctx_t.shape[-1] == self.K)
 
     def tables(self, device, M: int):
         if self.tile_part is None:
@@ -467,7 +480,7 @@ class CtxKVGroup:
         key = (ctx_t.data_ptr(), ctx_t._version, tuple(ctx_t.shape), ctx_t.dtype, torch.is_grad_enabled())
         st = self._pass
         if st is None or st.key != key:
-            factors = [p for l in self.layers for p in (l.lora_down.weight, l.lora_up.weight)]
+            factors = [p for l in self.layers for p in factor_weights(l)]
             st = self._pass = _CtxPass(key, None)
             st.kv = _CtxProjFn.apply(ctx_t, self, cdtype, st, *factors)
         return st

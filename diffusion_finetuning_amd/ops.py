@@ -11,12 +11,15 @@ nothing on a 288 GB part, and removes the per-call fp32→fp16 weight cast the r
 The cache is keyed on the weight's storage pointer, version counter, dtype and device, so `.to()`, `.half()`,
 `weight_apply_lora` or assigning a new Parameter invalidate it.
 """
+import os
 import warnings
 
 import torch
+import torch.distributed as dist
 from torch.autograd.function import once_differentiable
 
 from . import _native as nat
+from ._fastattr import factor_weights, frozen_linear, linear_params
 
 _warned_trainable_base = False
 
@@ -27,11 +30,11 @@ def _compute_dtype(weight: torch.Tensor) -> torch.dtype:
     return weight.dtype
 
 
-def _frozen_operands(module, cdtype: torch.dtype, need_wt: bool):
-    """Returns (W, Wᵀ|None, bias|None) in `cdtype`, building them once per (weight state, dtype)."""
-    lin = module.linear
-    w = lin.weight
-    b = lin.bias
+def _frozen_operands(module, cdtype: torch.dtype, need_wt: bool, w=None, b=None):
+    """Returns (W, Wᵀ|None, bias|None) in `cdtype`, building them once per (weight state, dtype); `w` / `b`: the frozen
+    Parameters when the caller has looked them up already."""
+    if w is None:
+        w, b = frozen_linear(module)
     key = (w.data_ptr(), w._version, w.dtype, w.device, cdtype,
            None if b is None else (b.data_ptr(), b._version))
     cache = module.__dict__.get("_dfa_cache")
@@ -122,23 +125,35 @@ class _AutoSink:
 
     def __init__(self, device):
         self.device = device
-        self.items = []
+        self.items = []       # (S, P, _SinkProblem) of the pass being run
         self.armed = False
         self.partials = None
-        self.tables = {}
+        self.shapes = {}      # everything of a problem but its two operand pointers → _SinkProblem
+        self.plans = {}       # the _SinkProblem objects of a whole pass, in order → _SinkPlan
 
     def defer(self, dy2, x2, t, u, scale, down, up, dtypes):
         """One layer: gB = s·dYᵀ·T → up, gA = s·Uᵀ·X → down."""
         M, N = dy2.shape
         K, r = x2.shape[1], t.shape[1]
-        self.defer_problem(dy2, 0, N, N, t, 0, r, r, False, M, scale, [(up, dtypes[1])])
-        self.defer_problem(x2, 0, K, K, u, 0, r, r, True, M, scale, [(down, dtypes[0])])
+        self.defer_problem(dy2, 0, N, N, t, 0, r, r, False, M, scale, ((up, dtypes[1]),))
+        self.defer_problem(x2, 0, K, K, u, 0, r, r, True, M, scale, ((down, dtypes[0]),))
 
     def defer_problem(self, S, s_off, s_stride, C, P, p_off, p_stride, rg, out_kn, M, scale, targets):
         """G[c, j] = scale·Σ_m S[m, s_off + c]·P[m, p_off + j] for len(targets)·rg rank columns; rank group i (rg columns) is
         the whole gradient of the Parameter targets[i][0] ([C, rg] for an `up`, [rg, C] for a `down` — out_kn), handed over
-        in targets[i][1].  Operands may be column slices of wider buffers (grouped projections)."""
-        self.items.append((S, s_off, s_stride, C, P, p_off, p_stride, rg, out_kn, M, scale, targets))
+        in targets[i][1].  Operands may be column slices of wider buffers (grouped projections).
+        A training loop defers the same problems every step, only on new activations: what does not change is kept as ONE
+        object per distinct problem, so that a whole pass is recognised by the identity of its objects (flush)."""
+        key = (s_off, s_stride, C, p_off, p_stride, rg, out_kn, M, scale, S.dtype, *[(id(p), dt) for p, dt in targets])
+        prob = self.shapes.get(key)
+        if prob is None:
+            if len(self.shapes) >= 4096:  # (a caller that keeps changing shapes or Parameters: start over)
+                self.shapes.clear()
+                self.plans.clear()
+            # (the object holds its Parameters: their ids in `key` cannot be reused while it lives)
+            prob = self.shapes[key] = _SinkProblem(s_off, s_stride, C, p_off, p_stride, rg, out_kn, M, scale, S.dtype,
+                                                   tuple(targets))
+        self.items.append((S, P, prob))
         if not self.armed:
             self.armed = True
             torch.autograd.Variable._execution_engine.queue_callback(self.flush)
@@ -147,39 +162,104 @@ class _AutoSink:
         items, self.items, self.armed = self.items, [], False
         if not items:
             return
-        offs, total = [], 0
-        for it in items:
-            C, rg, targets = it[3], it[7], it[11]
-            offs.append(total)
-            total += len(targets) * rg * C
-        stride = (total + 3) // 4 * 4
-        if self.partials is None or self.partials.shape[1] < stride:
-            self.partials = torch.empty((nat.GRAD_MAX_BLOCKS, stride), dtype=torch.float32, device=self.device)
-        part, pstride = self.partials, self.partials.shape[1]
-        grads = torch.empty(stride, dtype=torch.float32, device=self.device)
-        base = part.data_ptr()
-        by_dtype, rows = {}, []
-        for off, (S, s_off, s_stride, C, P, p_off, p_stride, rg, out_kn, M, scale, targets) in zip(offs, items):
-            n = len(targets)
-            outs = [base + 4 * (off + i * rg * C) for i in range(n)]
-            by_dtype.setdefault(S.dtype, []).append(
-                nat.grad_problem(S, s_off, s_stride, C, P, p_off, p_stride, n * rg, outs, rg, out_kn, pstride, M, scale))
-            rows.append([off, n * rg * C, nat.grad_row_blocks(M), 0])
-        for dt, probs in by_dtype.items():
-            nat.lora_grad_batched(probs, dt, self.device)
-        key = tuple(map(tuple, rows))
-        table = self.tables.get(key)  # (one host→device copy per distinct set of layer shapes, not one per step)
-        if table is None:
-            table = self.tables[key] = torch.tensor(rows, dtype=torch.int64).to(self.device)
-        nat.lora_fold_partials(table, len(rows), max(r_[1] for r_ in rows), part, pstride, grads, False)
-        for off, it in zip(offs, items):
-            C, rg, out_kn, targets = it[3], it[7], it[8], it[11]
-            for i, (p, dt) in enumerate(targets):
+        probs = tuple([it[2] for it in items])
+        plan = self.plans.get(probs)
+        if plan is None or plan.partials is not self.partials:
+            need = _SinkPlan.elements(probs)
+            if self.partials is None or self.partials.shape[1] < need:
+                self.plans.clear()  # (they point into the buffer this one replaces)
+                self.partials = torch.empty((nat.GRAD_MAX_BLOCKS, need), dtype=torch.float32, device=self.device)
+            if len(self.plans) >= 8:
+                self.plans.clear()
+            plan = self.plans[probs] = _SinkPlan(probs, self.partials, self.device)
+        plan.run([it[0].data_ptr() for it in items], [it[1].data_ptr() for it in items])
+
+
+class _SinkProblem:
+    """What a deferred factor-gradient problem is apart from the addresses of its two operands."""
+    __slots__ = ("s_off", "s_stride", "C", "p_off", "p_stride", "rg", "out_kn", "M", "scale", "dtype", "targets")
+
+    def __init__(self, *fields):
+        for name, value in zip(self.__slots__, fields):
+            setattr(self, name, value)
+
+
+class _SinkPlan:
+    """Everything `_AutoSink.flush` needs for one recurring backward pass, built once: the `lora_grad_problem` arrays (one per
+    operand dtype) with all fields filled in but the operand pointers, where each Parameter's gradient lies in the flat
+    result — Parameters of one shape side by side, so that a step hands its views over with one `view().unbind()` per shape
+    instead of a slice and a view per Parameter —, and the device table of the fold.  Per step: two pointer columns written
+    into the arrays (numpy, no Python loop over struct fields), the launches, one allocation for the result."""
+
+    @staticmethod
+    def elements(probs) -> int:
+        return (sum(len(q.targets) * q.rg * q.C for q in probs) + 3) // 4 * 4
+
+    def __init__(self, probs, partials, device):
+        import ctypes
+
+        import numpy as np
+
+        self.partials, self.device = partials, device
+        self.pstride = partials.shape[1]
+        self.stride = self.elements(probs)
+        # layout of the flat gradient: targets grouped by (shape, hand-over dtype), in first-seen order
+        slots = {}
+        for k, q in enumerate(probs):  # (a layer called twice in one pass defers the SAME object twice: slots go by position)
+            shape = (q.rg, q.C) if q.out_kn else (q.C, q.rg)
+            for i, (p, dt) in enumerate(q.targets):
+                slots.setdefault((shape, dt), []).append((k, i, p))
+        self.groups, where, off = [], {}, 0
+        for (shape, dt), members in slots.items():
+            n = shape[0] * shape[1]
+            self.groups.append((off, len(members), shape, dt, [p for _, _, p in members]))
+            for k, i, _ in members:
+                where[(k, i)] = off
+                off += n
+        assert off <= self.stride
+        base = partials.data_ptr()
+        rows, by_dtype = [], {}
+        for k, q in enumerate(probs):
+            by_dtype.setdefault(q.dtype, []).append(k)
+            for i in range(len(q.targets)):
+                rows.append([where[(k, i)], q.rg * q.C, nat.grad_row_blocks(q.M), 0])
+        self.launches = []
+        size = ctypes.sizeof(nat.GradProblem)
+        for dt, idx in by_dtype.items():
+            arr = (nat.GradProblem * len(idx))()
+            esize = torch.empty((), dtype=dt).element_size()
+            for slot, k in enumerate(idx):
+                q, g = probs[k], arr[slot]
+                for i in range(len(q.targets)):
+                    g.out[i] = base + 4 * where[(k, i)]
+                g.s_stride, g.p_stride, g.part_stride, g.M = q.s_stride, q.p_stride, self.pstride, q.M
+                g.C, g.r, g.rg, g.out_kn, g.n_blocks, g.scale = q.C, len(q.targets) * q.rg, q.rg, int(q.out_kn), 0, q.scale
+            raw = np.frombuffer(arr, dtype=np.uint8)
+            s_col = np.ndarray((len(idx),), dtype=np.uint64, buffer=raw, offset=nat.GradProblem.S.offset, strides=(size,))
+            p_col = np.ndarray((len(idx),), dtype=np.uint64, buffer=raw, offset=nat.GradProblem.P.offset, strides=(size,))
+            s_add = np.array([probs[k].s_off * esize for k in idx], dtype=np.uint64)
+            p_add = np.array([probs[k].p_off * 4 for k in idx], dtype=np.uint64)
+            self.launches.append((dt, arr, len(idx), np.array(idx, dtype=np.intp), s_col, p_col, s_add, p_add))
+        self.table = torch.tensor(rows, dtype=torch.int64).to(device)
+        self.n_rows, self.max_len = len(rows), max(r_[1] for r_ in rows)
+        self.np = np
+
+    def run(self, s_ptrs, p_ptrs):
+        np = self.np
+        s_all, p_all = np.array(s_ptrs, dtype=np.uint64), np.array(p_ptrs, dtype=np.uint64)
+        for dt, arr, n, idx, s_col, p_col, s_add, p_add in self.launches:
+            s_col[:] = s_all[idx] + s_add
+            p_col[:] = p_all[idx] + p_add
+            nat.lora_grad_batched_array(arr, n, dt, self.device)
+        grads = torch.empty(self.stride, dtype=torch.float32, device=self.device)
+        nat.lora_fold_partials(self.table, self.n_rows, self.max_len, self.partials, self.pstride, grads, False)
+        for off, n, shape, dt, params in self.groups:
+            views = grads[off:off + n * shape[0] * shape[1]].view(n, *shape)
+            if dt != torch.float32:
+                views = views.to(dt)
+            for p, g in zip(params, views.unbind(0)):
                 if not p.requires_grad:
                     continue  # (a factor frozen by the caller: autograd would not have produced its gradient either)
-                g = grads[off + i * rg * C: off + (i + 1) * rg * C].view((rg, C) if out_kn else (C, rg))
-                if dt != torch.float32:
-                    g = g.to(dt)
                 if p.grad is None:
                     p.grad = g
                 else:
@@ -220,7 +300,7 @@ class PackRegistry:
 
     @staticmethod
     def _sig(m):
-        d, u = m.lora_down.weight, m.lora_up.weight
+        d, u = factor_weights(m)
         return (d.data_ptr(), d._version, u.data_ptr(), u._version)
 
     def _current(self, members, cdtype, device) -> bool:
@@ -228,20 +308,23 @@ class PackRegistry:
         return (st is not None and self.table is not None and st[0] == cdtype and st[1] == device and
                 all(st[2][self.index[id(m)]] == self._sig(m) for m in members))
 
-    def get(self, module, cdtype):
+    def get(self, module, cdtype, d=None, u=None):
         i = self.index.get(id(module))
         if i is None:
             return None
-        d, u = module.lora_down.weight, module.lora_up.weight
+        if d is None:
+            d, u = factor_weights(module)
         if d.dtype != torch.float32 or u.dtype != torch.float32 or not d.is_cuda:
             return None  # (factors held in another dtype are cast per call, as before)
-        if not self._current((module,), cdtype, d.device) and not self._repack(cdtype, d.device):
+        st = self.state
+        if (st is None or self.table is None or st[0] != cdtype or st[1] != d.device or
+                st[2][i] != (d.data_ptr(), d._version, u.data_ptr(), u._version)) and not self._repack(cdtype, d.device):
             return None
         return self.views[i]
 
     def ensure(self, members, cdtype) -> bool:
         """True when the packed operands (a group's included) are current for `members` — refreshing them if needed."""
-        d = members[0].lora_down.weight
+        d = factor_weights(members[0])[0]
         if d.dtype != torch.float32 or not d.is_cuda:
             return False
         return self._current(members, cdtype, d.device) or self._repack(cdtype, d.device)
@@ -250,12 +333,14 @@ class PackRegistry:
         from .groups import QKVGroup, bind_ctx_views, bind_qkv_views, ctx_pack_rows, qkv_pack_rows
 
         mods = self.modules
-        if any(m.lora_down.weight.dtype != torch.float32 or m.lora_down.weight.device != device or
-               not m.lora_down.weight.is_contiguous() or not m.lora_up.weight.is_contiguous() for m in mods):
-            return False
+        facs = [factor_weights(m) for m in mods]  # (once per optimizer step, for every layer of the model: kept cheap)
+        for d, u in facs:
+            if d.dtype != torch.float32 or d.device != device or not d.is_contiguous() or not u.is_contiguous():
+                return False
         if torch.cuda.is_current_stream_capturing():
             return False
-        ptrs = tuple((m.lora_down.weight.data_ptr(), m.lora_up.weight.data_ptr()) for m in mods)
+        sigs = tuple([(d.data_ptr(), d._version, u.data_ptr(), u._version) for d, u in facs])
+        ptrs = tuple([(sg[0], sg[2]) for sg in sigs])
         if self.table is None or self.ptrs != ptrs or self.views is None or self.views[0][0].dtype != cdtype:
             # element offsets relative to ONE base pointer: the factors live in separate allocations, the pack kernel adds a
             # signed 64-bit offset to its `params` argument
@@ -291,14 +376,12 @@ class PackRegistry:
             self.ptrs = ptrs
             self.base = base
         nat.lora_pack_items(self.table, self.table.shape[0], self.maxlen, self.base.detach(), self.packed)
-        self.state = (cdtype, device, tuple(self._sig(m) for m in mods))
+        self.state = (cdtype, device, sigs)
         return True
 
 
 def register_pack_group(modules) -> None:
     """Called by `inject_trainable_lora` with the modules it wrapped (core.py)."""
-    import os
-
     if os.environ.get("DFA_PACK_REGISTRY", "1") == "0":
         return
     modules = list(modules)
@@ -312,18 +395,21 @@ def register_pack_group(modules) -> None:
 _auto_sinks = {}
 
 
+def deferral_open() -> bool:
+    """The process-wide half of `_auto_sink_for`: the switch is on and no process group is alive."""
+    return os.environ.get("DFA_DEFER_GRADS", "1") != "0" and not (dist.is_available() and dist.is_initialized())
+
+
+def param_defers(p) -> bool:
+    """The per-Parameter half: a leaf Parameter nobody hooked (a hook wants the gradient autograd would hand it)."""
+    return (isinstance(p, torch.nn.Parameter) and p.is_leaf and not p._backward_hooks and
+            not getattr(p, "_post_accumulate_grad_hooks", None))
+
+
 def _auto_sink_for(down, up):
     """The drop-in sink of the tensors' device, or None when deferring is not safe for these Parameters (see _AutoSink)."""
-    import os
-
-    import torch.distributed as dist
-
-    if os.environ.get("DFA_DEFER_GRADS", "1") == "0" or (dist.is_available() and dist.is_initialized()):
+    if not (deferral_open() and param_defers(down) and param_defers(up)):
         return None
-    for p in (down, up):
-        if not isinstance(p, torch.nn.Parameter) or not p.is_leaf or p._backward_hooks or \
-                getattr(p, "_post_accumulate_grad_hooks", None):
-            return None
     sink = _auto_sinks.get(down.device)
     if sink is None:
         sink = _auto_sinks[down.device] = _AutoSink(down.device)
@@ -491,7 +577,7 @@ class _GatedLinearFn(torch.autograd.Function):
 
 def _frozen_linear(lin, cdtype: torch.dtype):
     """(W, Wᵀ, bias) of a frozen nn.Linear in `cdtype`, cached on the module like _frozen_operands."""
-    w, b = lin.weight, lin.bias
+    w, b = linear_params(lin)
     key = (w.data_ptr(), w._version, w.dtype, w.device, cdtype, None if b is None else (b.data_ptr(), b._version))
     cache = lin.__dict__.get("_dfa_cache")
     if cache is None or cache["key"] != key:
@@ -517,35 +603,38 @@ def feed_forward_geglu(proj_module, lin2, x: torch.Tensor) -> torch.Tensor:
 def lora_linear(module, x: torch.Tensor, gate: bool = False) -> torch.Tensor:
     """Fused LoraInjectedLinear forward (lora_diffusion/lora.py:49-50) on the HIP device; `gate`: see lora_linear_geglu."""
     global _warned_trainable_base
-    lin, down, up = module.linear, module.lora_down.weight, module.lora_up.weight
-    if not x.is_cuda or not lin.weight.is_cuda:
+    w_param, b_param = frozen_linear(module)
+    down, up = factor_weights(module)
+    if not x.is_cuda or not w_param.is_cuda:
         raise RuntimeError(
             "LoraInjectedLinear.forward: the fused LoRA path runs only on a HIP device (MI355X); got input on "
-            f"{x.device} and weight on {lin.weight.device}. Move the model and inputs to 'cuda' — there is no CPU fallback."
+            f"{x.device} and weight on {w_param.device}. Move the model and inputs to 'cuda' — there is no CPU fallback."
         )
-    if lin.weight.requires_grad and torch.is_grad_enabled() and not _warned_trainable_base:
+    grad_on = torch.is_grad_enabled()
+    if w_param.requires_grad and grad_on and not _warned_trainable_base:
         _warned_trainable_base = True
         warnings.warn(
             "LoraInjectedLinear: the base weight has requires_grad=True, but this path treats W and b as frozen "
             "(no ∇W/∇b are produced). Call model.requires_grad_(False) before inject_trainable_lora as the "
             "reference trainers do."
         )
-    cdtype = _compute_dtype(lin.weight)
+    cdtype = _compute_dtype(w_param)
     shared = module.__dict__.get("_dfa_shared")  # (group, member): projections of one input called one by one (CLIP q/k/v)
     if shared is not None and not gate and shared[0].usable(x, cdtype) and x.dim() >= 2:
         from .groups import shared_projection
 
         return shared_projection(shared[0], shared[1], x, cdtype)
-    need_wt = torch.is_grad_enabled() and x.requires_grad
-    w, wt, bias = _frozen_operands(module, cdtype, need_wt)
-    sink = module.__dict__.get("_dfa_grad_sink")
-    packed = module.__dict__.get("_dfa_packed")
+    need_wt = grad_on and x.requires_grad
+    w, wt, bias = _frozen_operands(module, cdtype, need_wt, w_param, b_param)
+    attrs = module.__dict__
+    sink = attrs.get("_dfa_grad_sink")
+    packed = attrs.get("_dfa_packed")
     if packed is not None and packed[0].dtype != cdtype:
         packed = None
     if packed is None and sink is None:
-        reg = module.__dict__.get("_dfa_packreg")
+        reg = attrs.get("_dfa_packreg")
         if reg is not None:
-            packed = reg.get(module, cdtype)  # drop-in mode: all layers' packed factors from one launch per update
+            packed = reg.get(module, cdtype, down, up)  # drop-in mode: all layers' packed factors from one launch per update
     fn = _LoraProjGatedFn if gate == "pair" else (_LoraGegluFn if gate else _LoraLinearFn)
     return fn.apply(x, down, up, w, wt, bias, float(module.scale), sink, packed)
 

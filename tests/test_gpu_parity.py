@@ -1463,8 +1463,8 @@ def test_drop_in_backward_defers_factor_gradients_into_one_batched_launch(tiny_u
     _warm(plist, 5, 0.02)
     lat, noise, ts, ctx = orc.synthetic_batch(0, 2, 8, 6, 32)
     calls = []
-    real = nat.lora_grad_batched
-    monkeypatch.setattr(nat, "lora_grad_batched", lambda probs, dt, dev: (calls.append(len(probs)), real(probs, dt, dev))[1])
+    real = nat.lora_grad_batched_array
+    monkeypatch.setattr(nat, "lora_grad_batched_array", lambda arr, n, dt, dev: (calls.append(n), real(arr, n, dt, dev))[1])
 
     def backward():
         pred = unet(lat.to(DEV), ts.to(DEV), ctx.to(DEV)).sample
@@ -1501,6 +1501,64 @@ def test_drop_in_backward_defers_factor_gradients_into_one_batched_launch(tiny_u
     assert calls == []  # per-layer launches
     for p, g in zip(plist, deferred):
         assert relerr(p.grad, g) < 1e-5, relerr(p.grad, g)
+
+
+def test_drop_in_sink_plan_survives_a_layer_called_twice_and_a_frozen_factor(relerr, monkeypatch):
+    """The drop-in sink keeps ONE plan per recurring backward pass (ops._SinkPlan: problem arrays, result layout grouped by
+    Parameter shape, fold table) and only rewrites the operand pointers each step.  Cases a plan must not get wrong: the same
+    layer applied twice in one pass (the same problem object twice: two slots, the second hand-over accumulates), layers of
+    different shapes and row counts interleaved, a factor the caller froze (its .grad stays None), a second pass on new
+    activations (the plan is re-used), and a pass of a different composition afterwards (a new plan)."""
+    from diffusion_finetuning_amd import ops
+
+    torch.manual_seed(3)
+    a = dfa.LoraInjectedLinear(64, 128, bias=True, r=4).to(DEV)
+    b = dfa.LoraInjectedLinear(128, 64, bias=False, r=8).to(DEV)
+    for m in (a, b):
+        m.linear.requires_grad_(False)
+        with torch.no_grad():
+            m.lora_up.weight.normal_(0, 0.05)
+    b.lora_down.weight.requires_grad_(False)
+    plist = [a.lora_down.weight, a.lora_up.weight, b.lora_down.weight, b.lora_up.weight]
+
+    def backward(x1, x2, both=True):
+        h = b(a(x1).half()) if both else a(x1)
+        (h.float().square().mean() + a(x2).float().square().mean() * 0.5).backward()
+
+    def grads():
+        out = [None if p.grad is None else p.grad.clone() for p in plist]
+        for p in plist:
+            p.grad = None
+        return out
+
+    xs = [torch.randn(96, 64, device=DEV, dtype=torch.float16, requires_grad=True) for _ in range(2)]
+    ys = [torch.randn(96, 64, device=DEV, dtype=torch.float16, requires_grad=True) for _ in range(2)]
+    with torch.autocast("cuda", dtype=torch.float16):
+        backward(xs[0], xs[1])
+        sink = ops._auto_sinks[torch.device(DEV, torch.cuda.current_device())]
+        n_plans = len(sink.plans)
+        first = grads()
+        backward(ys[0], ys[1])
+        assert len(sink.plans) == n_plans  # same pass, new activations: the plan was re-used
+        second = grads()
+        backward(xs[0], xs[1], both=False)
+        assert len(sink.plans) == n_plans + 1
+        third = grads()
+        monkeypatch.setenv("DFA_DEFER_GRADS", "0")
+        backward(xs[0], xs[1])
+        want_first = grads()
+        backward(ys[0], ys[1])
+        want_second = grads()
+        backward(xs[0], xs[1], both=False)
+        want_third = grads()
+    for got, want in ((first, want_first), (second, want_second), (third, want_third)):
+        assert got[2] is None and want[2] is None  # the frozen factor
+        for g, w in zip(got, want):
+            if w is None:
+                assert g is None
+            else:
+                assert g.shape == w.shape and relerr(g, w) < 1e-5, relerr(g, w)
+    assert third[3] is None  # (b took no part in the third pass)
 
 
 def test_seeded_step_draws_timesteps_below_t_multiplier(tiny_unet_factory, monkeypatch):

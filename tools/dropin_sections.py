@@ -20,6 +20,7 @@ from diffusion_finetuning_amd import attention, groups, ops  # noqa: E402
 from diffusion_finetuning_amd.attention import set_use_memory_efficient_attention_xformers  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+CPROFILE = len(sys.argv) > 2 and sys.argv[2] == "cprofile"  # also: cProfile of 4 steps, top entries by own time
 args = types.SimpleNamespace(warmup=3, steps=steps, no_conv_autotune=False)
 bench.conv_autotune(args)
 device = torch.device("cuda", 0)
@@ -86,13 +87,17 @@ for i in range(args.warmup):
     step(i)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
+per_step = []
 for i in range(args.warmup, args.warmup + steps):
+    ts = time.perf_counter()
     step(i, clock=True)
+    per_step.append(1e3 * (time.perf_counter() - ts))
 t_enq = time.perf_counter() - t0
 torch.cuda.synchronize()
 t_all = time.perf_counter() - t0
 print(f"unchanged-trainer step: enqueue {1e3 * t_enq / steps:.2f} ms, drained {1e3 * t_all / steps:.2f} ms per step "
       f"({cfg['batch'] * steps / t_all:.1f} images/s)")
+print("  enqueue ms of every step: " + " ".join(f"{v:.1f}" for v in per_step))
 for k, v in sec.items():
     print(f"  host time in {k:38s} {1e3 * v / steps:7.2f} ms per step")
 
@@ -114,9 +119,23 @@ for cls in [ops._LoraLinearFn, ops._LoraGegluFn, ops._LoraProjGatedFn, ops._Gate
 for name in ("usable",):
     groups.QKVGroup.usable = timed("QKVGroup.usable", groups.QKVGroup.usable)
     groups.CtxKVGroup.usable = timed("CtxKVGroup.usable", groups.CtxKVGroup.usable)
+ops.PackRegistry._repack = timed("PackRegistry._repack (once per optimizer step: every layer's packed factors)", ops.PackRegistry._repack)
+ops._AutoSink.flush = timed("_AutoSink.flush (end of backward: batched factor gradients + .grad hand-over)", ops._AutoSink.flush)
 for i in range(args.warmup + steps, args.warmup + 2 * steps):
     step(i)
 torch.cuda.synchronize()
 print("per call (perf_counter wrappers; inner wrappers are included in the outer ones):")
 for k, (n, t) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
-    print(f"  {k:52s} {n / steps:6.1f} calls/step  {1e6 * t / n:8.1f} us each  {1e3 * t / steps:7.2f} ms per step")
+    print(f"  {k:82s} {n / steps:6.1f} calls/step  {1e6 * t / n:8.1f} us each  {1e3 * t / steps:7.2f} ms per step")
+
+if CPROFILE:
+    import cProfile
+    import pstats
+
+    prof = cProfile.Profile()
+    prof.enable()
+    for i in range(args.warmup, args.warmup + 4):
+        step(i)
+    prof.disable()
+    torch.cuda.synchronize()
+    pstats.Stats(prof).sort_stats("tottime").print_stats(60)
