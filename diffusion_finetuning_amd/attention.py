@@ -93,6 +93,8 @@ def _hip_forward(self, hidden_states, *args, **kwargs):
             k, v = k.to(q.dtype), v.to(q.dtype)
         out = core(q, k, v, heads, scale)
     for layer in self.to_out:  # linear (LoRA target), dropout
+        if type(layer) is nn.Dropout and layer.p == 0.0 and not layer._forward_hooks and not layer._forward_pre_hooks:
+            continue  # (the identity — Stable Diffusion's attention blocks are built with dropout 0.0 — without a module call)
         out = layer(out)
     return out
 

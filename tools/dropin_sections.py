@@ -116,6 +116,20 @@ for m in unet.modules():
 for cls in [ops._LoraLinearFn, ops._LoraGegluFn, ops._LoraProjGatedFn, ops._GatedLinearFn, groups._QKVProjFn, groups._FlashQKVFn,
             groups._CtxProjFn, groups._CtxAttnKVFn]:
     cls.backward = staticmethod(timed(f"{cls.__name__}.backward", cls.backward))
+if len(sys.argv) > 2 and sys.argv[2] == "fine":  # finer grain: forward bodies, the group entry points, the ctypes wrappers
+    from diffusion_finetuning_amd import _native as nat
+
+    for cls in [ops._LoraLinearFn, ops._LoraGegluFn, ops._LoraProjGatedFn, ops._GatedLinearFn, groups._QKVProjFn, groups._FlashQKVFn,
+                groups._CtxProjFn, groups._CtxAttnKVFn]:
+        cls.forward = staticmethod(timed(f"{cls.__name__}.forward (body only, inside apply)", cls.forward))
+    for fn in ("qkv_self_attention", "ctx_cross_attention"):
+        wrapped = timed(f"groups.{fn} (apply calls included)", getattr(groups, fn))
+        setattr(groups, fn, wrapped)
+        setattr(attention, fn, wrapped)
+    for fn in ("lora_linear_fwd", "lora_linear_geglu_fwd", "lora_linear_bwd_input", "lora_gemm_packed", "attn_flash_fwd_qkv",
+               "attn_flash_bwd_qkv", "attn_ctx_fwd_kv", "attn_ctx_bwd_kv", "geglu_linear_bwd", "lora_gemm_parts"):
+        if hasattr(nat, fn):
+            setattr(nat, fn, timed(f"_native.{fn} (allocations + one ctypes call)", getattr(nat, fn)))
 for name in ("usable",):
     groups.QKVGroup.usable = timed("QKVGroup.usable", groups.QKVGroup.usable)
     groups.CtxKVGroup.usable = timed("CtxKVGroup.usable", groups.CtxKVGroup.usable)
