@@ -22,7 +22,7 @@ from torch import nn
 from . import _native as nat
 from ._fastattr import factor_weights, linear_params
 from .groups import ctx_cross_attention, qkv_self_attention
-from .ops import feed_forward_geglu
+from .ops import feed_forward_geglu, lora_tail
 from .sandwich import ctx_attention, flash_attention
 
 ATTENTION_CLASS_NAMES = {"CrossAttention", "Attention"}
@@ -83,16 +83,24 @@ def _hip_forward(self, hidden_states, *args, **kwargs):
     # slices of the shared buffers (groups.py).
     qkv = self.__dict__.get("_dfa_qkv")
     kvg = self.__dict__.get("_dfa_ctx")
+    layers = list(self.to_out)  # linear (LoRA target), dropout
     if self_attention and qkv is not None and qkv.usable(hidden_states, cdtype) and nat.attn_flash_supported(*shape):
-        out = qkv_self_attention(qkv, hidden_states, heads, scale, cdtype)
+        # (the grouped paths run `to_out[0]` inside the attention core's autograd node when it is a plain wrapped layer)
+        tail = lora_tail(layers[0], cdtype) if layers else None
+        out = qkv_self_attention(qkv, hidden_states, heads, scale, cdtype, tail)
+        if tail is not None:
+            del layers[0]
     elif not self_attention and kvg is not None and core is ctx_attention and kvg[0].usable(ctx, cdtype):
-        out = ctx_cross_attention(kvg[0], kvg[1], to_q(hidden_states), ctx, heads, scale, cdtype)
+        tail = lora_tail(layers[0], cdtype) if layers else None
+        out = ctx_cross_attention(kvg[0], kvg[1], to_q(hidden_states), ctx, heads, scale, cdtype, tail)
+        if tail is not None:
+            del layers[0]
     else:
         q, k, v = to_q(hidden_states), self.to_k(ctx), self.to_v(ctx)
         if q.dtype != k.dtype:  # mixed module dtypes outside autocast: compute in the query's dtype
             k, v = k.to(q.dtype), v.to(q.dtype)
         out = core(q, k, v, heads, scale)
-    for layer in self.to_out:  # linear (LoRA target), dropout
+    for layer in layers:
         if type(layer) is nn.Dropout and layer.p == 0.0 and not layer._forward_hooks and not layer._forward_pre_hooks:
             continue  # (the identity — Stable Diffusion's attention blocks are built with dropout 0.0 — without a module call)
         out = layer(out)

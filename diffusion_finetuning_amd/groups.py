@@ -241,101 +241,130 @@ class _QKVProjFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, group, cdtype, *factors):  # factors: the (down, up) Parameters, listed so autograd tracks them
-        K, N3, rr = group.K, group.G * group.N, group.G * group.r
-        x2 = x.reshape(-1, K)
-        if x2.dtype != cdtype:
-            x2 = x2.to(cdtype)
-        if not x2.is_contiguous():
-            x2 = x2.contiguous()
-        w, wt = group.frozen.get(cdtype, ctx.needs_input_grad[0])  # Wᵀ only when a dX launch will follow
-        M = x2.shape[0]
-        qkv = torch.empty((M, N3), dtype=cdtype, device=x2.device)
-        t = torch.empty((M, rr), dtype=torch.float32, device=x2.device)
-        scale = _same_scale(group.layers)
-        if group.wide:
-            if not nat.lora_gemm_parts(x2, w, group.frozen.bias(cdtype), group.Fa, group.Qb, qkv, t, rr, M, K, N3, group.r,
-                                       group.G, False, scale):
-                raise RuntimeError("grouped q/k/v forward: lora_gemm_parts has no kernel for this shape")
-        else:
-            nat.lora_gemm_packed(x2, K, w, group.frozen.bias(cdtype), group.Fa, group.Qb, None, None, 0, qkv, t, M, K, N3, rr,
-                                 scale)
+        x2, t, qkv = _qkv_project(ctx, x, group, cdtype)
         ctx.save_for_backward(x2, t)
-        ctx.group, ctx.wt, ctx.scale = group, wt, scale
-        ctx.x_shape, ctx.x_dtype = x.shape, x.dtype
-        return qkv.view(*x.shape[:-1], N3)
+        return qkv.view(*x.shape[:-1], qkv.shape[1])
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dqkv):
-        g = ctx.group
         x2, t = ctx.saved_tensors
-        K, N, N3, r, rr = g.K, g.N, g.G * g.N, g.r, g.G * g.r
-        d2 = dqkv.reshape(-1, N3)
-        if d2.dtype != x2.dtype:
-            d2 = d2.to(x2.dtype)
-        if not d2.is_contiguous():
-            d2 = d2.contiguous()
-        M = d2.shape[0]
-        need_dx = ctx.needs_input_grad[0]
-        u = torch.empty((M, rr), dtype=torch.float32, device=d2.device)
-        u_by_part = False  # U layout: [M, 3r] (member g in columns g·r ..) or, from per-member launches, [3][M, r]
-        dx2 = None
-        if need_dx:
-            if ctx.wt is None:
-                raise RuntimeError("grouped q/k/v backward: Wᵀ operand was not prepared in forward")
-            dx2 = torch.empty((M, K), dtype=d2.dtype, device=d2.device)
-            if g.wide:
-                if not nat.lora_gemm_parts(d2, ctx.wt, None, g.Fb, g.Qa, dx2, u, rr, M, N3, K, r, g.G, True, ctx.scale):
-                    raise RuntimeError("grouped q/k/v backward: lora_gemm_parts has no kernel for this shape")
-            else:
-                nat.lora_gemm_packed(d2, N3, ctx.wt, None, g.Fb, g.Qa, None, None, 0, dx2, u, M, N3, K, rr, ctx.scale)
-        elif g.wide:
-            # no dX wanted (the first block of a model: its input carries no gradient): U_g = dY_g·B_g from the members'
-            # own packed factors, one small launch each on the column slices of the shared gradient buffer
-            u, u_by_part = u.view(g.G, M, r), True
-            for i in range(g.G):
-                nat.lora_gemm_packed(d2[:, i * N:(i + 1) * N], N3, None, None, g.Fb_part[i], None, None, None, 0, None, u[i],
-                                     M, N, 0, r, ctx.scale)
+        return _qkv_project_backward(ctx, x2, t, dqkv)
+
+
+def _qkv_project(ctx, x, group, cdtype):
+    """Forward body of a grouped q/k/v projection for the autograd node `ctx` (which saves what it needs itself): returns
+    (x2 [M,K], T [M,G·r] fp32, qkv [M,G·N])."""
+    K, N3, rr = group.K, group.G * group.N, group.G * group.r
+    x2 = x.reshape(-1, K)
+    if x2.dtype != cdtype:
+        x2 = x2.to(cdtype)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    w, wt = group.frozen.get(cdtype, ctx.needs_input_grad[0])  # Wᵀ only when a dX launch will follow
+    M = x2.shape[0]
+    qkv = torch.empty((M, N3), dtype=cdtype, device=x2.device)
+    t = torch.empty((M, rr), dtype=torch.float32, device=x2.device)
+    scale = _same_scale(group.layers)
+    if group.wide:
+        if not nat.lora_gemm_parts(x2, w, group.frozen.bias(cdtype), group.Fa, group.Qb, qkv, t, rr, M, K, N3, group.r,
+                                   group.G, False, scale):
+            raise RuntimeError("grouped q/k/v forward: lora_gemm_parts has no kernel for this shape")
+    else:
+        nat.lora_gemm_packed(x2, K, w, group.frozen.bias(cdtype), group.Fa, group.Qb, None, None, 0, qkv, t, M, K, N3, rr,
+                             scale)
+    ctx.group, ctx.wt, ctx.scale = group, wt, scale
+    ctx.x_shape, ctx.x_dtype = x.shape, x.dtype
+    return x2, t, qkv
+
+
+def _qkv_project_backward(ctx, x2, t, dqkv):
+    """Backward body: one fused dX launch (when the input wants a gradient), the factor gradients deferred; returns the
+    node's gradient tuple for (x, group, cdtype, *factors)."""
+    g = ctx.group
+    K, N, N3, r, rr = g.K, g.N, g.G * g.N, g.r, g.G * g.r
+    d2 = dqkv.reshape(-1, N3)
+    if d2.dtype != x2.dtype:
+        d2 = d2.to(x2.dtype)
+    if not d2.is_contiguous():
+        d2 = d2.contiguous()
+    M = d2.shape[0]
+    need_dx = ctx.needs_input_grad[0]
+    u = torch.empty((M, rr), dtype=torch.float32, device=d2.device)
+    u_by_part = False  # U layout: [M, 3r] (member g in columns g·r ..) or, from per-member launches, [3][M, r]
+    dx2 = None
+    if need_dx:
+        if ctx.wt is None:
+            raise RuntimeError("grouped q/k/v backward: Wᵀ operand was not prepared in forward")
+        dx2 = torch.empty((M, K), dtype=d2.dtype, device=d2.device)
+        if g.wide:
+            if not nat.lora_gemm_parts(d2, ctx.wt, None, g.Fb, g.Qa, dx2, u, rr, M, N3, K, r, g.G, True, ctx.scale):
+                raise RuntimeError("grouped q/k/v backward: lora_gemm_parts has no kernel for this shape")
         else:
-            nat.lora_gemm_packed(d2, N3, None, None, g.Fb, None, None, None, 0, None, u, M, N3, 0, rr, ctx.scale)
-        g.grads.note(M, need_dx)
-        for i in range(g.G):  # gB_i = s·dY_iᵀ·T_i : column slices of the shared buffers
-            g.grads.defer([i], True, d2, i * N, N3, N, t, i * r, rr, M, ctx.scale, (d2, t))
-        # gA = s·Uᵀ·X: as many members per problem as fit 16 accumulator columns (rank groups of r → their `down` gradients);
-        # all three at rank <= 5 — X read once — two + one at rank 8, one each at rank 16
-        per = 1 if u_by_part else max(1, RANK_PAD // r)
-        for c in range(0, g.G, per):
-            mem = list(range(c, min(c + per, g.G)))
-            off, ld = (c * M * r, r) if u_by_part else (c * r, rr)
-            g.grads.defer(mem, False, x2, 0, K, K, u, off, ld, M, ctx.scale, (x2, u))
-        dx = None
-        if need_dx:
-            dx = dx2.view(ctx.x_shape)
-            if dx.dtype != ctx.x_dtype:
-                dx = dx.to(ctx.x_dtype)
-        return (dx, None, None) + (None,) * (2 * g.G)
+            nat.lora_gemm_packed(d2, N3, ctx.wt, None, g.Fb, g.Qa, None, None, 0, dx2, u, M, N3, K, rr, ctx.scale)
+    elif g.wide:
+        # no dX wanted (the first block of a model: its input carries no gradient): U_g = dY_g·B_g from the members'
+        # own packed factors, one small launch each on the column slices of the shared gradient buffer
+        u, u_by_part = u.view(g.G, M, r), True
+        for i in range(g.G):
+            nat.lora_gemm_packed(d2[:, i * N:(i + 1) * N], N3, None, None, g.Fb_part[i], None, None, None, 0, None, u[i],
+                                 M, N, 0, r, ctx.scale)
+    else:
+        nat.lora_gemm_packed(d2, N3, None, None, g.Fb, None, None, None, 0, None, u, M, N3, 0, rr, ctx.scale)
+    g.grads.note(M, need_dx)
+    for i in range(g.G):  # gB_i = s·dY_iᵀ·T_i : column slices of the shared buffers
+        g.grads.defer([i], True, d2, i * N, N3, N, t, i * r, rr, M, ctx.scale, (d2, t))
+    # gA = s·Uᵀ·X: as many members per problem as fit 16 accumulator columns (rank groups of r → their `down` gradients);
+    # all three at rank <= 5 — X read once — two + one at rank 8, one each at rank 16
+    per = 1 if u_by_part else max(1, RANK_PAD // r)
+    for c in range(0, g.G, per):
+        mem = list(range(c, min(c + per, g.G)))
+        off, ld = (c * M * r, r) if u_by_part else (c * r, rr)
+        g.grads.defer(mem, False, x2, 0, K, K, u, off, ld, M, ctx.scale, (x2, u))
+    dx = None
+    if need_dx:
+        dx = dx2.view(ctx.x_shape)
+        if dx.dtype != ctx.x_dtype:
+            dx = dx.to(ctx.x_dtype)
+    return (dx, None, None) + (None,) * (2 * g.G)
 
 
-class _FlashQKVFn(torch.autograd.Function):
-    """Self-attention core on the q | k | v column slices of one [B,T,3·H·d] buffer; backward writes dq | dk | dv as the
-    column slices of one buffer — the dY of `_QKVProjFn`, no split / cat copies either way."""
+class _QKVAttnFn(torch.autograd.Function):
+    """The grouped q/k/v projection (`_QKVProjFn`'s two bodies) and the self-attention core on the q | k | v column slices of
+    its [B,T,3·H·d] output as ONE autograd node: backward writes dq | dk | dv as the column slices of one buffer — the dY of the
+    projection, no split / cat copies either way.  What a self-attention module's forward uses (`qkv_self_attention`); through
+    round 5 projection and core were a node each (≈ 25 µs of host time per node on the unchanged-trainer route)."""
 
     @staticmethod
-    def forward(ctx, qkv, heads, scale):
-        q = qkv if qkv.is_contiguous() else qkv.contiguous()
-        need = ctx.needs_input_grad[0]
-        out, lse = nat.attn_flash_fwd_qkv(q, heads, scale, want_lse=need)
+    def forward(ctx, x, group, cdtype, heads, attn_scale, tail, *factors):
+        # factors: the members' (down, up) Parameters, then — with a `tail` (ops.LoraTail: the module's `to_out[0]`, run here
+        # behind the core) — that layer's two
+        x2, t, qkv = _qkv_project(ctx, x, group, cdtype)
+        qkv = qkv.view(*x.shape[:-1], qkv.shape[1])
+        need = any(ctx.needs_input_grad)
+        out, lse = nat.attn_flash_fwd_qkv(qkv, heads, attn_scale, want_lse=need)
+        ctx.heads, ctx.attn_scale, ctx.tail = heads, attn_scale, tail
+        if tail is None:
+            if need:
+                ctx.save_for_backward(x2, t, qkv, out, lse)
+            return out
+        y, kept = tail.forward(out, ctx.needs_input_grad[-2], ctx.needs_input_grad[-1])
         if need:
-            ctx.save_for_backward(q, out, lse)
-        ctx.heads, ctx.scale = heads, scale
-        return out
+            ctx.save_for_backward(x2, t, qkv, out, lse, *kept)
+        return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
-        q, out, lse = ctx.saved_tensors
-        return nat.attn_flash_bwd_qkv(q, out, dout if dout.is_contiguous() else dout.contiguous(), lse, ctx.heads,
-                                      ctx.scale), None, None
+        x2, t, qkv, out, lse, *kept = ctx.saved_tensors
+        tail_grads = ()
+        if ctx.tail is not None:
+            dout, g_down, g_up = ctx.tail.backward(dout, *kept)
+            tail_grads = (g_down, g_up)
+        dqkv = nat.attn_flash_bwd_qkv(qkv, out, dout if dout.is_contiguous() else dout.contiguous(), lse, ctx.heads,
+                                      ctx.attn_scale)
+        grads = _qkv_project_backward(ctx, x2, t, dqkv)
+        return grads[:3] + (None, None, None) + grads[3:] + tail_grads
 
 
 class _SplitQKVFn(torch.autograd.Function):
@@ -373,13 +402,15 @@ def shared_projection(group: QKVGroup, member: int, x: torch.Tensor, cdtype: tor
     return out
 
 
-def qkv_self_attention(group: QKVGroup, x: torch.Tensor, heads: int, scale: Optional[float], cdtype: torch.dtype):
-    """softmax(q kᵀ·scale) v for q, k, v = the group's three LoRA projections of x → [B, T, H·d]."""
+def qkv_self_attention(group: QKVGroup, x: torch.Tensor, heads: int, scale: Optional[float], cdtype: torch.dtype, tail=None):
+    """softmax(q kᵀ·scale) v for q, k, v = the group's three LoRA projections of x → [B, T, H·d]; with a `tail` (ops.LoraTail
+    of the module's `to_out[0]`) that layer's output instead, from the same autograd node."""
     factors = [p for l in group.layers for p in factor_weights(l)]
-    qkv = _QKVProjFn.apply(x, group, cdtype, *factors)
+    if tail is not None:
+        factors += tail.factors
     if scale is None:
         scale = (group.N // heads) ** -0.5
-    return _FlashQKVFn.apply(qkv, heads, float(scale))
+    return _QKVAttnFn.apply(x, group, cdtype, heads, float(scale), tail, *factors)
 
 
 class _CtxPass:
@@ -550,20 +581,32 @@ class _CtxAttnKVFn(torch.autograd.Function):
     and nothing is ever added or copied."""
 
     @staticmethod
-    def forward(ctx, q, kv, group, state, index, heads, scale):
+    def forward(ctx, q, kv, group, state, index, heads, scale, tail, *tail_factors):
+        # tail: ops.LoraTail of the module's `to_out[0]` (run here, behind the core; its two factors in tail_factors) or None
         q = q if q.is_contiguous() else q.contiguous()
         off_k, off_v = group.off[2 * index], group.off[2 * index + 1]
         out = nat.attn_ctx_fwd_kv(q, kv, off_k, off_v, heads, scale)
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            ctx.save_for_backward(q, kv)
-            state.consumers += 1
-        ctx.state, ctx.offs, ctx.heads, ctx.scale = state, (off_k, off_v), heads, scale
+        kept = ()
+        if tail is not None:
+            out, kept = tail.forward(out, ctx.needs_input_grad[-2], ctx.needs_input_grad[-1])
+        ctx.core = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]  # (else only the tail's factors want a gradient)
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(q, kv, *kept)
+            if ctx.core:
+                state.consumers += 1
+        ctx.state, ctx.offs, ctx.heads, ctx.scale, ctx.tail = state, (off_k, off_v), heads, scale, tail
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
-        q, kv = ctx.saved_tensors
+        q, kv, *kept = ctx.saved_tensors
+        tail_grads = ()
+        if ctx.tail is not None:
+            dout, g_down, g_up = ctx.tail.backward(dout, *kept)
+            tail_grads = (g_down, g_up)
+        if not ctx.core:
+            return (None,) * 8 + tail_grads
         st = ctx.state
         if st.dkv is None:
             st.dkv = torch.zeros_like(kv)
@@ -575,14 +618,18 @@ class _CtxAttnKVFn(torch.autograd.Function):
             # the last consumer hands the buffer over and closes the pass: a second backward over the same graph
             # (retain_graph) starts counting — and filling a fresh buffer — again
             dkv, st.dkv, st.returned = st.dkv, None, 0
-        return dq, dkv, None, None, None, None, None
+        return (dq, dkv, None, None, None, None, None, None) + tail_grads
 
 
 def ctx_cross_attention(group: CtxKVGroup, index: int, q: torch.Tensor, ctx_t: torch.Tensor, heads: int,
-                        scale: Optional[float], cdtype: torch.dtype) -> torch.Tensor:
+                        scale: Optional[float], cdtype: torch.dtype, tail=None) -> torch.Tensor:
+    """Cross-attention of module `index` of the group on its query projection `q`; with a `tail` (ops.LoraTail of the module's
+    `to_out[0]`) that layer's output instead, from the same autograd node."""
     st = group.project(ctx_t, cdtype)
     if scale is None:
         scale = (q.shape[-1] // heads) ** -0.5
     if q.dtype != cdtype:
         q = q.to(cdtype)
-    return _CtxAttnKVFn.apply(q, st.kv, group, st, index, heads, float(scale))
+    if tail is None:
+        return _CtxAttnKVFn.apply(q, st.kv, group, st, index, heads, float(scale), None)
+    return _CtxAttnKVFn.apply(q, st.kv, group, st, index, heads, float(scale), tail, *tail.factors)

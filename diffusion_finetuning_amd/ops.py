@@ -72,42 +72,101 @@ class _LoraLinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, down, up, w, wt, bias, scale, grad_sink, packed):
-        K = w.shape[1]
-        N = w.shape[0]
-        x2 = x.reshape(-1, K)
-        if x2.dtype != w.dtype:
-            x2 = x2.to(w.dtype)
-        if not x2.is_contiguous():
-            x2 = x2.contiguous()
-        a = _as_f32(down)
-        b = _as_f32(up)
-        # packed factors: the trainer keeps them current for the whole slab (one launch per optimizer step);
-        # otherwise they are cast here, once per call, like autocast casts lora_down/lora_up in the reference
-        packs = packed if packed is not None else nat.lora_pack_factors(a, b, w.dtype)
-        y2, t = nat.lora_linear_fwd(x2, w, bias, a, b, scale, packs)
-        ctx.save_for_backward(x2, a, b, t)
-        ctx.packs = packs
-        ctx.wt = wt
-        ctx.scale = float(scale)
-        ctx.x_shape = x.shape
-        ctx.x_dtype = x.dtype
-        ctx.factor_dtypes = (down.dtype, up.dtype)
-        ctx.grad_sink = grad_sink
-        ctx.auto_sink = _auto_sink_for(down, up) if grad_sink is None else None
-        ctx.params = (down, up) if ctx.auto_sink is not None else None
-        return y2.view(*x.shape[:-1], N)
+        y, saved = _lora_forward(ctx, x, down, up, w, wt, bias, scale, grad_sink, packed)
+        ctx.save_for_backward(*saved)
+        return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x2, a, b, t = ctx.saved_tensors
-        N = b.shape[0]
-        dy2 = dy.reshape(-1, N)
-        if dy2.dtype != x2.dtype:
-            dy2 = dy2.to(x2.dtype)
-        if not dy2.is_contiguous():
-            dy2 = dy2.contiguous()
-        return (*_lora_backward(ctx, x2, a, b, t, dy2), None, None, None, None, None, None)
+        return (*_lora_backward_of(ctx, dy, *ctx.saved_tensors), None, None, None, None, None, None)
+
+
+def _lora_forward(ctx, x, down, up, w, wt, bias, scale, grad_sink, packed):
+    """Forward body of one fused LoRA linear for the autograd node (or the LoraTail of a node) `ctx`: the launch, and on `ctx`
+    everything but tensors that `_lora_backward` reads.  Returns (y, (x2, a, b, t)) — the tuple is what the node must save."""
+    K = w.shape[1]
+    N = w.shape[0]
+    x2 = x.reshape(-1, K)
+    if x2.dtype != w.dtype:
+        x2 = x2.to(w.dtype)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    a = _as_f32(down)
+    b = _as_f32(up)
+    # packed factors: the trainer keeps them current for the whole slab (one launch per optimizer step);
+    # otherwise they are cast here, once per call, like autocast casts lora_down/lora_up in the reference
+    packs = packed if packed is not None else nat.lora_pack_factors(a, b, w.dtype)
+    y2, t = nat.lora_linear_fwd(x2, w, bias, a, b, scale, packs)
+    ctx.packs = packs
+    ctx.wt = wt
+    ctx.scale = float(scale)
+    ctx.x_shape = x.shape
+    ctx.x_dtype = x.dtype
+    ctx.factor_dtypes = (down.dtype, up.dtype)
+    ctx.grad_sink = grad_sink
+    ctx.auto_sink = _auto_sink_for(down, up) if grad_sink is None else None
+    ctx.params = (down, up) if ctx.auto_sink is not None else None
+    return y2.view(*x.shape[:-1], N), (x2, a, b, t)
+
+
+def _lora_backward_of(ctx, dy, x2, a, b, t):
+    """Backward body: (dx, g_down, g_up) for the incoming gradient `dy` of the layer's output."""
+    N = b.shape[0]
+    dy2 = dy.reshape(-1, N)
+    if dy2.dtype != x2.dtype:
+        dy2 = dy2.to(x2.dtype)
+    if not dy2.is_contiguous():
+        dy2 = dy2.contiguous()
+    return _lora_backward(ctx, x2, a, b, t, dy2)
+
+
+class LoraTail:
+    """One LoraInjectedLinear run INSIDE another autograd node, behind that node's own kernels — `to_out[0]` of an attention
+    module behind the attention core (groups._QKVAttnFn, groups._CtxAttnKVFn).  Same launches as `_LoraLinearFn`, one
+    `Function.apply` and one backward node fewer per layer (≈ 25 µs of host time on the unchanged-trainer route, which is
+    host-bound).  The object carries what `lora_linear` looked up for the layer (`operands`) and, between forward and
+    backward, the non-tensor state `_lora_backward` reads; the tensors to keep are returned to the node, which saves them
+    with its own (`ctx.save_for_backward`: the version checks of the factors stay in force).  The two factor Parameters are
+    inputs of the node (`factors`), so autograd tracks them exactly as it does for `_LoraLinearFn`."""
+
+    def __init__(self, operands):
+        self.operands = operands  # (down, up, w, wt, bias, scale, grad_sink, packed): what `lora_linear` hands `_LoraLinearFn`
+        self.state = None
+
+    @property
+    def factors(self):
+        return self.operands[0], self.operands[1]
+
+    def forward(self, x, need_down: bool, need_up: bool):
+        """(y, tensors the node must save) for the layer's input `x` (an internal tensor of the node)."""
+        self.state = _TailState((True, need_down, need_up))
+        return _lora_forward(self.state, x, *self.operands)
+
+    def backward(self, dy, x2, a, b, t):
+        """(dx, g_down | None, g_up | None): the gradient of the layer's input, and of its factors where they are not deferred."""
+        return _lora_backward_of(self.state, dy, x2, a, b, t)
+
+
+class _TailState:
+    """The `ctx` a LoraTail shows `_lora_forward` / `_lora_backward`: plain attributes."""
+
+    def __init__(self, needs_input_grad):
+        self.needs_input_grad = needs_input_grad
+
+
+def lora_tail(module, cdtype: torch.dtype):
+    """A LoraTail for `module` — or None when the layer is not a plain LoraInjectedLinear on the HIP device (a subclass, an
+    overridden forward, forward hooks, a CLIP-style shared projection): such a layer is simply called."""
+    from .core import LoraInjectedLinear
+
+    if (type(module) is not LoraInjectedLinear or "forward" in module.__dict__ or module._forward_hooks or
+            module._forward_pre_hooks or "_dfa_shared" in module.__dict__):
+        return None
+    w_param, b_param = frozen_linear(module)
+    if not w_param.is_cuda or (w_param.requires_grad and torch.is_grad_enabled()):
+        return None  # (lora_linear raises / warns for these: let it)
+    return LoraTail(_layer_operands(module, cdtype, torch.is_grad_enabled(), w_param, b_param, *factor_weights(module)))
 
 
 class _AutoSink:
@@ -500,14 +559,17 @@ class _LoraGegluFn(torch.autograd.Function):
         return (*_lora_backward(ctx, x2, a, b, t, dy2), None, None, None, None, None, None)
 
 
-class _LoraProjGatedFn(torch.autograd.Function):
-    """The `proj` LoraInjectedLinear of a GEGLU block for a caller that also owns what follows the gate (feed_forward below):
-    ONE launch produces y = [h | g] — the differentiable output, whose gradient is the usual LoRA backward — and the gated
-    activation h·gelu(g) as a non-differentiable by-product."""
+class _FeedForwardFn(torch.autograd.Function):
+    """z = (h·gelu(g))·W2ᵀ + b2 with [h | g] = x·Wᵀ + b + s·(x·Aᵀ)·Bᵀ — diffusers FeedForward with a GEGLU activation,
+    `net[2](net[0](x))`: the `proj` LoraInjectedLinear with the gate in its forward epilogue (ONE launch writes y = [h | g] and
+    the gated activation), the frozen second linear layer on the gated activation, and in backward ONE launch for
+    dY = gate-backward(dz·W2, y) (`geglu_linear_bwd`: the gate's backward sits in the epilogue of the linear layer's
+    backward-input GEMM) followed by the usual LoRA backward.  One autograd node for the whole block (through round 5 the two
+    halves were a node each; the host-bound unchanged-trainer route pays ≈ 25 µs per node)."""
 
     @staticmethod
-    def forward(ctx, x, down, up, w, wt, bias, scale, grad_sink, packed):
-        K = w.shape[1]
+    def forward(ctx, x, down, up, w, wt, bias, scale, grad_sink, packed, w2, w2t, b2):
+        K, N = w.shape[1], w.shape[0]
         x2 = x.reshape(-1, K)
         if x2.dtype != w.dtype:
             x2 = x2.to(w.dtype)
@@ -517,12 +579,12 @@ class _LoraProjGatedFn(torch.autograd.Function):
         b = _as_f32(up)
         packs = packed if packed is not None else nat.lora_pack_factors(a, b, w.dtype)
         res = nat.lora_linear_geglu_fwd(x2, w, bias, a.shape[0], scale, packs, True)
-        if res is None:
+        if res is None:  # no fused kernel for this shape / dtype: the two launches it stands for
             y2, t = nat.lora_linear_fwd(x2, w, bias, a, b, scale, packs)
-            out = nat.geglu_gate_fwd(y2)
+            gated = nat.geglu_gate_fwd(y2)
         else:
-            out, y2, t = res
-        ctx.save_for_backward(x2, a, b, t)
+            gated, y2, t = res
+        ctx.save_for_backward(x2, a, b, t, y2, w2, w2t)
         ctx.packs = packs
         ctx.wt = wt
         ctx.scale = float(scale)
@@ -532,47 +594,21 @@ class _LoraProjGatedFn(torch.autograd.Function):
         ctx.grad_sink = grad_sink
         ctx.auto_sink = _auto_sink_for(down, up) if grad_sink is None else None
         ctx.params = (down, up) if ctx.auto_sink is not None else None
-        N = w.shape[0]
-        out = out.view(*x.shape[:-1], N // 2)
-        ctx.mark_non_differentiable(out)
-        return y2.view(*x.shape[:-1], N), out
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, dy, _dout):
-        x2, a, b, t = ctx.saved_tensors
-        dy2 = dy.reshape(-1, b.shape[0])
-        if dy2.dtype != x2.dtype:
-            dy2 = dy2.to(x2.dtype)
-        if not dy2.is_contiguous():
-            dy2 = dy2.contiguous()
-        return (*_lora_backward(ctx, x2, a, b, t, dy2), None, None, None, None, None, None)
-
-
-class _GatedLinearFn(torch.autograd.Function):
-    """z = gated @ W2ᵀ + b2 with gated = h·gelu(g) of y = [h | g] (diffusers FeedForward: net[2](net[0](x))), W2 / b2 frozen.
-    The graph edge goes to y, not to `gated`: backward is ONE launch, dY = gate-backward(dz·W2, y) (`geglu_linear_bwd`) —
-    the gate's backward sits in the epilogue of the linear layer's backward-input GEMM."""
-
-    @staticmethod
-    def forward(ctx, y, gated, w2, w2t, b2):
-        ctx.save_for_backward(y, w2, w2t)
-        return torch.nn.functional.linear(gated, w2, b2)
+        return torch.nn.functional.linear(gated.view(*x.shape[:-1], N // 2), w2, b2)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dz):
-        y, w2, w2t = ctx.saved_tensors
-        y2 = y.reshape(-1, y.shape[-1])
+        x2, a, b, t, y2, w2, w2t = ctx.saved_tensors
         dz2 = dz.reshape(-1, dz.shape[-1])
         if dz2.dtype != y2.dtype:
             dz2 = dz2.to(y2.dtype)
         if not dz2.is_contiguous():
             dz2 = dz2.contiguous()
-        dy = nat.geglu_linear_bwd(dz2, w2t, y2)
-        if dy is None:  # no fused kernel for this shape / dtype: the two steps it stands for
-            dy = nat.geglu_gate_bwd(y2, dz2 @ w2)
-        return dy.view(y.shape), None, None, None, None
+        dy2 = nat.geglu_linear_bwd(dz2, w2t, y2)
+        if dy2 is None:  # no fused kernel for this shape / dtype: the two steps it stands for
+            dy2 = nat.geglu_gate_bwd(y2, dz2 @ w2)
+        return (*_lora_backward(ctx, x2, a, b, t, dy2), None, None, None, None, None, None, None, None, None)
 
 
 def _frozen_linear(lin, cdtype: torch.dtype):
@@ -595,13 +631,13 @@ def feed_forward_geglu(proj_module, lin2, x: torch.Tensor) -> torch.Tensor:
     """diffusers FeedForward with a GEGLU activation — `net[2](net[0](x))`, net[0] = GEGLU(proj), net[2] = frozen Linear — with
     BOTH halves of the gate inside GEMM epilogues: forward in the `proj` launch, backward in the launch that computes net[2]'s
     input gradient.  `proj_module` is the LoraInjectedLinear, `lin2` the nn.Linear."""
-    y, gated = lora_linear(proj_module, x, gate="pair")
-    w2, w2t, b2 = _frozen_linear(lin2, y.dtype)
-    return _GatedLinearFn.apply(y, gated, w2, w2t, b2)
+    return lora_linear(proj_module, x, gate=lin2)
 
 
-def lora_linear(module, x: torch.Tensor, gate: bool = False) -> torch.Tensor:
-    """Fused LoraInjectedLinear forward (lora_diffusion/lora.py:49-50) on the HIP device; `gate`: see lora_linear_geglu."""
+def lora_linear(module, x: torch.Tensor, gate=False) -> torch.Tensor:
+    """Fused LoraInjectedLinear forward (lora_diffusion/lora.py:49-50) on the HIP device.  `gate`: False — the plain layer;
+    True — with the GEGLU gate behind it (lora_linear_geglu); the frozen nn.Linear that follows the gate — the whole
+    feed-forward block (feed_forward_geglu)."""
     global _warned_trainable_base
     w_param, b_param = frozen_linear(module)
     down, up = factor_weights(module)
@@ -624,7 +660,16 @@ def lora_linear(module, x: torch.Tensor, gate: bool = False) -> torch.Tensor:
         from .groups import shared_projection
 
         return shared_projection(shared[0], shared[1], x, cdtype)
-    need_wt = grad_on and x.requires_grad
+    operands = _layer_operands(module, cdtype, grad_on and x.requires_grad, w_param, b_param, down, up)
+    if gate is False or gate is True:
+        return (_LoraGegluFn if gate else _LoraLinearFn).apply(x, *operands)
+    # `gate` is the frozen nn.Linear that follows the gate (feed_forward_geglu): the whole block as one node
+    return _FeedForwardFn.apply(x, *operands, *_frozen_linear(gate, cdtype))
+
+
+def _layer_operands(module, cdtype, need_wt: bool, w_param, b_param, down, up):
+    """(down, up, W, Wᵀ | None, bias, scale, grad_sink, packed factors | None) of one wrapped layer: the argument list of the
+    LoRA autograd nodes behind the input."""
     w, wt, bias = _frozen_operands(module, cdtype, need_wt, w_param, b_param)
     attrs = module.__dict__
     sink = attrs.get("_dfa_grad_sink")
@@ -635,8 +680,7 @@ def lora_linear(module, x: torch.Tensor, gate: bool = False) -> torch.Tensor:
         reg = attrs.get("_dfa_packreg")
         if reg is not None:
             packed = reg.get(module, cdtype, down, up)  # drop-in mode: all layers' packed factors from one launch per update
-    fn = _LoraProjGatedFn if gate == "pair" else (_LoraGegluFn if gate else _LoraLinearFn)
-    return fn.apply(x, down, up, w, wt, bias, float(module.scale), sink, packed)
+    return down, up, w, wt, bias, float(module.scale), sink, packed
 
 
 def lora_linear_geglu(module, x: torch.Tensor) -> torch.Tensor:

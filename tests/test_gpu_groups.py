@@ -927,6 +927,44 @@ def test_clip_attention_projections_share_one_launch(relerr, monkeypatch):
     assert torch.isfinite(l8).all()
 
 
+def test_attention_tail_layer_with_a_hooked_factor_returns_its_gradients(relerr, monkeypatch):
+    """`to_out[0]` of an attention module runs INSIDE the attention core's autograd node on the grouped paths (ops.LoraTail).
+    Its factor gradients are normally deferred (drop-in sink / slab); a factor somebody hooked — `Parameter.register_hook`, what
+    DDP-style consumers of AccumulateGrad rely on — must get a real gradient through autograd instead: the node then RETURNS
+    the two gradients at the tail's input positions.  One self-attention and one cross-attention `to_out[0].lora_up` are
+    hooked; every `.grad` (and what the hooks saw) must equal the ungrouped run's, where the layer is its own node."""
+    def run(grouped):
+        monkeypatch.setenv("DFA_DROPIN_GROUPS", "1" if grouped else "0")
+        unet = _tiny64().to(DEV)
+        params, _ = dfa.inject_trainable_lora(unet, r=4)
+        plist = list(itertools.chain(*params))
+        _warm(plist)
+        set_use_memory_efficient_attention_xformers(unet, True)
+        seen = {}
+        hooked = []
+        for name, m in unet.named_modules():
+            if name.endswith("attn1") or name.endswith("attn2"):
+                if len([h for h in hooked if h.endswith(name[-5:])]) == 0:
+                    p = m.to_out[0].lora_up.weight
+                    p.register_hook(lambda g, key=name: seen.__setitem__(key, g.detach().clone()))
+                    hooked.append(name)
+        assert len(hooked) == 2
+        lat, noise, ts, ctx = orc.synthetic_batch(0, 2, 8, 6, 64)
+        with torch.autocast("cuda", dtype=torch.float16):
+            pred = unet(lat.to(DEV), ts.to(DEV), ctx.to(DEV)).sample
+        dfa.ddpm_mse_loss(pred.float(), noise.to(DEV).float()).backward()
+        n_groups = len([m for m in unet.modules() if "_dfa_qkv" in m.__dict__])
+        return torch.cat([p.grad.reshape(-1) for p in plist]).cpu(), {k: v.cpu() for k, v in seen.items()}, n_groups
+
+    got, seen_g, n_g = run(True)
+    want, seen_u, n_u = run(False)
+    assert n_g == 4 and n_u == 0
+    assert relerr(got, want) < 5e-3, relerr(got, want)
+    assert set(seen_g) == set(seen_u) and len(seen_g) == 2
+    for k in seen_g:
+        assert seen_g[k].shape == seen_u[k].shape and relerr(seen_g[k], seen_u[k]) < 5e-3, (k, relerr(seen_g[k], seen_u[k]))
+
+
 @pytest.mark.parametrize("r", [4, 8])
 def test_unchanged_trainer_loop_gets_grouped_projections(relerr, monkeypatch, r):
     """The reference's loop as written (train_lora_dreambooth.py:595-598,623-625,659-676,811-888 under fp16 mixed precision):

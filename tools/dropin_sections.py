@@ -40,7 +40,11 @@ from diffusion_finetuning_amd.trainer import ddpm_tables  # noqa: E402
 sa, sb = ddpm_tables(device=device)
 data = bench.synthetic_steps(args.warmup + 2 * steps, cfg["batch"], cfg["latent"], 0, 1, device)
 
-acc = collections.defaultdict(lambda: [0, 0.0])
+acc = collections.defaultdict(lambda: [0, 0.0, []])
+# the autograd nodes of the route (names differ between the trees this tool compares: take what the tree has)
+FUNCTIONS = [getattr(m, n) for m, n in [(ops, "_LoraLinearFn"), (ops, "_LoraGegluFn"), (ops, "_LoraProjGatedFn"), (ops, "_GatedLinearFn"),
+                                         (ops, "_FeedForwardFn"), (groups, "_QKVProjFn"), (groups, "_FlashQKVFn"), (groups, "_QKVAttnFn"),
+                                         (groups, "_CtxProjFn"), (groups, "_CtxAttnKVFn")] if hasattr(m, n)]
 
 
 def timed(name, fn):
@@ -49,9 +53,11 @@ def timed(name, fn):
         try:
             return fn(*a, **k)
         finally:
+            dt = time.perf_counter() - t0
             e = acc[name]
             e[0] += 1
-            e[1] += time.perf_counter() - t0
+            e[1] += dt
+            e[2].append(dt)
     return wrapper
 
 
@@ -97,7 +103,7 @@ torch.cuda.synchronize()
 t_all = time.perf_counter() - t0
 print(f"unchanged-trainer step: enqueue {1e3 * t_enq / steps:.2f} ms, drained {1e3 * t_all / steps:.2f} ms per step "
       f"({cfg['batch'] * steps / t_all:.1f} images/s)")
-print("  enqueue ms of every step: " + " ".join(f"{v:.1f}" for v in per_step))
+print("  enqueue ms of every step: " + " ".join(f"{v:.1f}" for v in per_step) + f"   (fastest {min(per_step):.2f}, median {sorted(per_step)[len(per_step) // 2]:.2f})")
 for k, v in sec.items():
     print(f"  host time in {k:38s} {1e3 * v / steps:7.2f} ms per step")
 
@@ -113,14 +119,12 @@ for m in unet.modules():
         m.__dict__["forward"] = timed("attention hook (to_q/k/v + core + to_out)", f)
     elif f is not None and getattr(f, "func", None) is getattr(attention, "_hip_feed_forward", None):
         m.__dict__["forward"] = timed("feed-forward hook (proj + gate + net.2)", f)
-for cls in [ops._LoraLinearFn, ops._LoraGegluFn, ops._LoraProjGatedFn, ops._GatedLinearFn, groups._QKVProjFn, groups._FlashQKVFn,
-            groups._CtxProjFn, groups._CtxAttnKVFn]:
+for cls in FUNCTIONS:
     cls.backward = staticmethod(timed(f"{cls.__name__}.backward", cls.backward))
 if len(sys.argv) > 2 and sys.argv[2] == "fine":  # finer grain: forward bodies, the group entry points, the ctypes wrappers
     from diffusion_finetuning_amd import _native as nat
 
-    for cls in [ops._LoraLinearFn, ops._LoraGegluFn, ops._LoraProjGatedFn, ops._GatedLinearFn, groups._QKVProjFn, groups._FlashQKVFn,
-                groups._CtxProjFn, groups._CtxAttnKVFn]:
+    for cls in FUNCTIONS:
         cls.forward = staticmethod(timed(f"{cls.__name__}.forward (body only, inside apply)", cls.forward))
     for fn in ("qkv_self_attention", "ctx_cross_attention"):
         wrapped = timed(f"groups.{fn} (apply calls included)", getattr(groups, fn))
@@ -138,9 +142,12 @@ ops._AutoSink.flush = timed("_AutoSink.flush (end of backward: batched factor gr
 for i in range(args.warmup + steps, args.warmup + 2 * steps):
     step(i)
 torch.cuda.synchronize()
-print("per call (perf_counter wrappers; inner wrappers are included in the outer ones):")
-for k, (n, t) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
-    print(f"  {k:82s} {n / steps:6.1f} calls/step  {1e6 * t / n:8.1f} us each  {1e3 * t / steps:7.2f} ms per step")
+print("per call (perf_counter wrappers; inner wrappers are included in the outer ones; the MEDIAN call is what compares between runs — "
+      "the host's speed drifts by ±10 % within a minute on a shared box):")
+for k, (n, t, each) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+    each.sort()
+    print(f"  {k:82s} {n / steps:6.1f} calls/step  {1e6 * t / n:8.1f} us each (median {1e6 * each[len(each) // 2]:6.1f})  "
+          f"{1e3 * t / steps:7.2f} ms per step")
 
 if CPROFILE:
     import cProfile
