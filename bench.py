@@ -934,12 +934,16 @@ def main():
                 import subprocess
 
                 torch.cuda.empty_cache()
-                cmd = [sys.executable, os.path.abspath(__file__), "--drop-in", "--steps", str(args.steps), "--warmup", str(args.warmup)]
+                # (the route is host-bound and the host's speed wanders by several percent within seconds on a shared box: at least
+                #  30 timed steps — 1.2 s — whatever the headline's K)
+                cmd = [sys.executable, os.path.abspath(__file__), "--drop-in", "--steps", str(max(30, args.steps)),
+                       "--warmup", str(max(5, args.warmup))]
                 out = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, timeout=600)
                 line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
                 d = json.loads(line)
-                result["extra"] = {"drop_in": {"images_s": d["value"], "ms_per_step": d["ms_per_step"], "final_loss": d["final_loss"],
-                                               "route": d["route"], "measured_in": "a fresh child process (bench.py --drop-in)"}}
+                result["extra"] = {"drop_in": {"images_s": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                                               "final_loss": d["final_loss"], "route": d["route"],
+                                               "measured_in": "a fresh child process (bench.py --drop-in)"}}
             except Exception as exc:
                 log(f"drop-in route in a child process failed ({exc!r}); measuring it in this process")
                 try:
