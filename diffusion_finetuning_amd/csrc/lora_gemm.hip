@@ -1257,10 +1257,17 @@ int gate_tile_width(int64_t tiles_m, int cols, bool gated) {
     return c160 < c128 ? 160 : 128;
 }
 
+// tools/gemm_bench.py / tools/skeleton_per_class.py ablations (GemmParams::dbg): read once, applied by every launcher
+static int gemm_dbg_env() {
+    static const int v = [] { const char* e = getenv("LORA_GEMM_DBG"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 // GEGLU-gated forward: the two-stage ring kernel, a tile = BN/2 h columns + their BN/2 g columns.
 template <typename T, int BN>
 int launch_gate_bn(GemmParams p, hipStream_t stream) {
     constexpr int BM = 128;
+    p.dbg = gemm_dbg_env();
     p.tiles_m = (int)((p.M + BM - 1) / BM);
     p.tiles_n = p.gateF / (BN / 2);
     p.ldp = p.r;
@@ -1285,6 +1292,7 @@ int launch_gate(GemmParams p, hipStream_t stream) {
 template <typename T, int BN>
 int launch_gate_bwd_bn(GemmParams p, hipStream_t stream) {
     constexpr int BM = 128;
+    p.dbg = gemm_dbg_env();
     p.tiles_m = (int)((p.M + BM - 1) / BM);
     p.tiles_n = p.Nc / BN;
     p.ldp = p.r;
